@@ -1,0 +1,185 @@
+/* sd_amd.h — C ABI of libsdamd.so: MI355X (gfx950) kernels for the contrastive training hot path of
+ * SeanNobel/speech-decoding (BrainEncoder + CLIPLoss + Classifier).
+ *
+ * The reference is pure Python/PyTorch and has no FFI of its own: what a binding
+ * would replace are the aten calls made by
+ *     speech_decoding/models.py:45-65    SpatialAttention.forward      -> sda_sa_weights_*, sda_conv_gemm
+ *     speech_decoding/models.py:111-117  SubjectBlock.forward          -> sda_conv_gemm (widx = subject)
+ *     speech_decoding/models.py:152-166  ConvBlock.forward             -> sda_conv_gemm, sda_bn_*, sda_glu_*
+ *     speech_decoding/models.py:191-196  BrainEncoder.forward          -> sda_conv_gemm (GELU epilogue)
+ *     speech_decoding/utils/loss.py:58-79 CLIPLoss.forward (fast path) -> sda_rows_sumsq, sda_conv_gemm
+ *                                                                         (split-K), sda_clip_ce, sda_wgrad_gemm
+ *     speech_decoding/models.py:208-248  Classifier.forward            -> sda_clip_ce (ranks output)
+ * and their autograd backward.  Every entry point takes plain device pointers, sizes and a
+ * hipStream_t (passed as void*); no torch types cross this boundary.  All functions return 0 on
+ * success and a negative code on failure; sda_last_error() gives the message.
+ *
+ * Activation "row layout" (RL): a (B, C, T) tensor is stored channels-last as rows of Cp elements,
+ *     row(b, t) = b * (T + SDA_ROW_PAD) + SDA_ROW_PAD + t,        Cp = C rounded up to 64,
+ * with all padding rows / channels equal to zero, in a buffer of sda_rows_alloc(B, T) rows.
+ */
+#ifndef SD_AMD_H
+#define SD_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDA_ABI_VERSION 1
+#define SDA_ROW_PAD 16
+#define SDA_CH_ALIGN 64
+
+enum { SDA_F32 = 0, SDA_BF16 = 1 };
+
+/* conv_gemm epilogue flags */
+enum { SDA_EPI_GELU = 1 };
+
+int sda_abi_version(void);
+const char* sda_last_error(void);
+long sda_rows_alloc(int B, int T);
+int sda_pad_channels(int C);
+
+/* (B, C, T) fp32 contiguous  ->  RL rows of Cp elements of `dtype` (channel padding zero-filled; pad
+ * rows are NOT touched: the caller zero-initialises the buffer once). */
+int sda_pack_rows(const float* src, void* dst, int B, int C, int T, int Cp, int dtype, void* stream);
+/* RL -> (B, C, T) fp32 contiguous */
+int sda_unpack_rows(const void* src, float* dst, int B, int C, int T, int Cp, int dtype, void* stream);
+/* (B, C, T) of `dtype`... not provided: gradients enter/leave in RL. */
+
+/* per-sample sum of squares over an RL tensor viewed as B rows of `row_elems` contiguous elements with
+ * pitch `pitch` (elements). out[b] fp32. `scratch` holds B*64 floats. */
+int sda_rows_sumsq(const void* x, float* out, float* scratch, int B, long row_elems, long pitch,
+                   int dtype, void* stream);
+
+/* fp32 conv weight [nW][Cout][Cin][KS]  ->  packed `dtype` operand.
+ * mode 0 (forward):  dst[n][tap][co'][ci]  = w[n][co][ci][tap]
+ * mode 1 (dgrad):    dst[n][tap][ci][co']  = w[n][co][ci][KS-1-tap]
+ * co' = co if glu_half == 0, else (co < glu_half ? co : glu_half_p + (co - glu_half)).
+ * Rows/cols beyond the source extent are zero. Cout_p/Cin_p are the padded extents of co'/ci. */
+int sda_pack_conv_weight(const float* w, void* dst, int nW, int Cout, int Cin, int KS, int Cout_p,
+                         int Cin_p, int mode, int glu_half, int glu_half_p, int dtype, void* stream);
+/* fp32 vector [C] -> padded fp32 [Cp] with the same GLU remap */
+int sda_pack_vector(const float* v, float* dst, int C, int Cp, int glu_half, int glu_half_p, void* stream);
+/* inverse of mode 0 for gradients: fp32 [nW][KS][Cout_p][Cin_p] -> fp32 [nW][Cout][Cin][KS] */
+int sda_unpack_conv_wgrad(const float* g, float* dst, int nW, int Cout, int Cin, int KS, int Cout_p,
+                          int Cin_p, int glu_half, int glu_half_p, void* stream);
+int sda_unpack_vector(const float* g, float* dst, int C, int Cp, int glu_half, int glu_half_p, void* stream);
+
+/* Implicit-GEMM 1-D convolution, kernel size 1 or 3, stride 1, "same" zero padding, dilation <= 16:
+ *   y[b, t, co] = bias[co] + sum_{tap, ci} x[b, t + (tap - KS/2) * dil, ci] * w[widx[b]][tap][co][ci]  (+ res[b, t, co])
+ * Serves the forward convolutions, the data gradients (weights packed with mode 1) and, with
+ * ksplit > 1, the B x B similarity matmul of the loss (raw fp32 partial slabs, no epilogue). */
+typedef struct sda_conv_args {
+  const void* x;        /* RL [rows][x_pitch]; contraction over Cin_p elements of each row */
+  const void* w;        /* packed [nW][KS][Cout_p][w_pitch] */
+  const float* bias;    /* [Cout_p] or NULL */
+  const void* res;      /* RL [rows][Cout_p] residual added in the epilogue, or NULL */
+  void* y;              /* RL [rows][Cout_p] output (post-activation when SDA_EPI_GELU) */
+  void* y_pre;          /* with SDA_EPI_GELU: pre-activation output, or NULL */
+  const int32_t* widx;  /* [B] weight selector per sample (device), or NULL */
+  float* stats;         /* [B * n_t_tiles][2][Cout_p] per-tile (sum, sum of squares) over valid rows, or NULL */
+  float* partial;       /* ksplit > 1: [ksplit][T][Cout_p] fp32 raw accumulators (B must be 1) */
+  int B, T, Cin_p, Cout_p, KS, dil;
+  long x_pitch, w_pitch; /* elements per row of x / per output-channel row of w */
+  long x_row0;           /* first row of sample 0 (SDA_ROW_PAD for RL, 0 for plain matrices) */
+  long x_sample_rows;    /* rows between consecutive samples (T + SDA_ROW_PAD for RL) */
+  long x_rows_limit;     /* rows >= limit read as zero */
+  int w_rows_limit;      /* output channels >= limit read as zero (Cout_p when fully padded) */
+  int ksplit;            /* >= 1 */
+  int flags, dtype;
+} sda_conv_args;
+int sda_conv_gemm(const sda_conv_args* a, void* stream);
+int sda_conv_n_t_tiles(int T);
+
+/* BatchNorm1d (training statistics) over valid rows.
+ * finalize: per-tile partial (sum, sumsq) -> mean/rstd, fused affine scale/shift, running-stat update
+ * (momentum, unbiased variance) when running_mean != NULL.  In eval mode call with ntiles = 0 and the
+ * running stats: scale/shift are derived from them. */
+int sda_bn_finalize(const float* partial, int ntiles, double count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                    float* rstd, float* scale, float* shift, int C, int Cp, int training, void* stream);
+/* y = GELU(x * scale[c] + shift[c]) on valid rows */
+int sda_bn_gelu_forward(const void* x, void* y, const float* scale, const float* shift, int B, int T,
+                        int Cp, int dtype, void* stream);
+/* backward of y = GELU(BN(x)) (training statistics), two calls so that data-parallel ranks can
+ * all-reduce the sums in between:  dg = dy * GELU'(u);
+ * reduce: dbeta = sum dg, dgamma = sum dg*xhat over this rank's valid rows (fp32 [Cp]; ordered
+ *         two-stage reduction through `partial`, sda_reduce_scratch_floats(Cp) floats);
+ * apply:  dx = gamma*rstd*(dg - dbeta/count - xhat*dgamma/count), count = GLOBAL number of rows. */
+int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, int C, float* partial, float* dgamma,
+                                float* dbeta, int B, int T, int Cp, int dtype, void* stream);
+int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int C, const float* dgamma,
+                               const float* dbeta, double count, void* dx, int B, int T, int Cp, int dtype,
+                               void* stream);
+int sda_reduce_scratch_floats(int Cp);
+
+/* GLU over channels: y[:, c] = x[:, c] * sigmoid(x[:, Ch + c]), x has 2*Ch channels (models.py:164) */
+int sda_glu_forward(const void* x, void* y, int B, int T, int Ch, int dtype, void* stream);
+int sda_glu_backward(const void* x, const void* dy, void* dx, int B, int T, int Ch, int dtype, void* stream);
+/* du = dz * GELU'(u) */
+int sda_gelu_backward(const void* u, const void* dz, void* du, int B, int T, int Cp, int dtype, void* stream);
+/* column sums of an RL tensor over valid rows: out[c] = sum_{b,t} x[b,t,c]  (bias gradients) */
+int sda_colsum(const void* x, float* out, float* scratch /* sda_reduce_scratch_floats(Cp) */, int B, int T,
+               int Cp, int dtype, void* stream);
+
+/* Weight-gradient GEMM:  g[seg][tap][co][ci] = sum_{b in seg} sum_t dy[b,t,co] * x[b, t+(tap-KS/2)*dil, ci]
+ * Samples are visited through `perm` (device int32 [B]); segment s covers perm[seg_start[s]..seg_start[s+1]).
+ * Output fp32 slabs [nseg][KS][Cout_p][Cin_p].  With out_e != NULL (KS must be 1, nseg 1) the result is
+ * written as `dtype` rows instead:  out_e[co][ci] = acc - rscale[co] * sub[co][ci]   (loss backward dZ). */
+typedef struct sda_wgrad_args {
+  const void* dy;       /* RL [rows][dy_pitch] */
+  const void* x;        /* RL [rows][x_pitch] */
+  float* g;             /* [nseg][KS][Cout_p][Cin_p] fp32 */
+  void* out_e;          /* optional typed output [Cout rows][out_pitch] */
+  const void* sub;      /* optional [Cout rows][out_pitch] */
+  const float* rscale;  /* optional [Cout] */
+  const int32_t* perm;
+  const int32_t* seg_start; /* device int32 [nseg + 1] */
+  int nseg, B, T, Cout_p, Cin_p, KS, dil;
+  long dy_pitch, x_pitch, out_pitch;
+  long row0, sample_rows; /* as in sda_conv_args */
+  long rows_limit;        /* rows of x at or beyond this index read as zero */
+  int co_valid;           /* rows of out_e to write (out_e mode) */
+  int dtype;
+} sda_wgrad_args;
+int sda_wgrad_gemm(const sda_wgrad_args* a, void* stream);
+/* dst[i] = sum_s src[s][i] in fixed order */
+int sda_reduce_slabs(const float* src, float* dst, int nslabs, long n, void* stream);
+
+/* SpatialAttention weights (models.py:49-58 with SpatialDropout 81-84 folded in):
+ * a = Re(z) cos + Im(z) sin; W = softmax_c(a); Wd = W * mask.  z is complex64 interleaved (re, im).
+ * Outputs: W fp32 [D1][C] (saved for backward) and the packed operand Wp `dtype` [D1p][Cp]. */
+int sda_sa_weights_forward(const float* z, const float* cos_t, const float* sin_t, const float* mask,
+                           float* W, void* Wp, int D1, int K2, int C, int D1p, int Cp, int dtype, void* stream);
+/* dWd fp32 [D1p][Cp] (from sda_wgrad_gemm) -> dz complex64 interleaved [D1][K2].
+ * cosT/sinT are the transposed tables [C][K2] (constant buffers, transposed once by the host). */
+int sda_sa_weights_backward(const float* dWd, const float* W, const float* mask, const float* cosT,
+                            const float* sinT, float* dz, int D1, int K2, int C, int Cp, void* stream);
+
+/* CLIP loss tail on the raw similarity S[i][j] = <Y_i, Z_j> (rows = speech, loss.py:60-79):
+ * logits = S / (|Y_i| |Z_j|) * exp(temp); per-row (max, sumexp) over the local column block, per-column
+ * lse over all rows, and diag[i] = logits[i][i - col0] for rows whose positive lives in this block.
+ * Multi-GPU: rows are global (Bm), columns are this rank's Bn samples starting at global index col0;
+ * zsq holds the Bn local norms. */
+int sda_clip_logits_stats(const float* S, long s_pitch, const float* ysq, const float* zsq, const float* temp,
+                          float* logits, float* row_max, float* row_sum, float* col_lse, float* diag,
+                          int Bm, int Bn, int col0, void* stream);
+/* Given the final row lse (after any cross-rank merge): D = dloss/dlogits, G[i][j] = D * exp(temp) /
+ * (|Y_i||Z_j|) stored as `dtype` with pitch g_pitch, rscale[j] = sum_i D_ij logits_ij / |Z_j|^2,
+ * scalars[0] = this block's share of the loss, scalars[1] = its share of dloss/dtemp.
+ * inv_norm = 1/(2*B_global) for reduction="mean", 1/2 for "sum".  colpart: 2*Bn floats of scratch. */
+int sda_clip_grad(const float* logits, const float* row_lse, const float* col_lse, const float* ysq,
+                  const float* zsq, const float* temp, float inv_norm, int col0, void* G, long g_pitch,
+                  float* rscale, float* colpart, float* scalars, int Bm, int Bn, int dtype, void* stream);
+/* cnt[i] = #{local j : logits[i][j] beats diag[i]} (ties: lower global index wins) — Classifier ranks */
+int sda_clip_ranks(const float* logits, const float* diag, int32_t* cnt, int Bm, int Bn, int col0, void* stream);
+int sda_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SD_AMD_H */

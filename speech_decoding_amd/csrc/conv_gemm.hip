@@ -1,0 +1,262 @@
+// conv_gemm — implicit-GEMM dilated Conv1d (kernel 1 or 3) on MFMA, channels-last rows.
+//
+// Reference ops this replaces: every nn.Conv1d on the path — models.py:97-109 (1x1 + per-subject 1x1),
+// models.py:128-150 (k=3 dilated), models.py:188-189 (final 1x1) — their input gradients (same kernel
+// on mode-1 packed weights), SpatialAttention's channel mix (models.py:65) and, with ksplit > 1, the
+// similarity matmul of loss.py:68.
+//
+// One workgroup (256 threads = 4 waves as 2(t) x 2(co)) computes a 128-row x TILE_CO-channel output
+// tile of one sample.  K loop over 128-byte slabs of input channels: the (128 + 2*dil)-row input slab
+// and the KS x TILE_CO weight slab are staged into XOR-swizzled LDS; every MFMA operand is a 16-byte
+// ds_read_b128 (8 bf16 / 4 fp32 along the contraction).  The three taps reuse the same input slab
+// at row offsets tap*dil.  D[row = t][col = co] accumulates in fp32.
+// Epilogue: bias in registers -> LDS staging -> coalesced pass adding the residual, optional GELU,
+// BatchNorm partial statistics (per tile, deterministic), 8/16-byte stores.
+#include "sd_common.h"
+
+namespace sda {
+
+constexpr int XS_BYTES = (TILE_T + 2 * PAD) * 128;
+constexpr int EP_ROWS = 64;
+
+template <int TILE_CO> struct EpiGeom {
+  static constexpr int STRIDE = TILE_CO + 4;          // floats; == 4 (mod 8): conflict-free D writes
+  static constexpr int NCH = TILE_CO / 4;             // 4-channel chunks per row
+  static constexpr int RG = 256 / NCH;                // row groups
+  static constexpr int EP_BYTES = EP_ROWS * STRIDE * 4;
+  static constexpr int RED_BYTES = RG * TILE_CO * 2 * 4;
+};
+
+template <int TILE_CO, int KS> constexpr int conv_lds_bytes() {
+  constexpr int main_b = XS_BYTES + KS * TILE_CO * 128;
+  constexpr int epi_b = EpiGeom<TILE_CO>::EP_BYTES + EpiGeom<TILE_CO>::RED_BYTES;
+  return main_b > epi_b ? main_b : epi_b;
+}
+
+template <typename E, int TILE_CO, int KS>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a, const int n_t_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int SLAB = Elem<E>::SLAB;
+  constexpr int PER16 = Elem<E>::PER16;
+  constexpr int NREP = TILE_CO / 32;
+  constexpr int HALF_CO = TILE_CO / 2;
+  using G = EpiGeom<TILE_CO>;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wave_t = wid >> 1, wave_c = wid & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int n_co = a.Cout_p / TILE_CO;
+  const int co_tile = bid % n_co; bid /= n_co;
+  const int t_tile = bid % n_t_tiles; bid /= n_t_tiles;
+  const int b = bid % a.B;
+  const int ks = bid / a.B;
+  const int co0 = co_tile * TILE_CO;
+  const int t0 = t_tile * TILE_T;
+  const int dil = a.dil;
+  const int halo = (KS == 3) ? dil : 0;
+
+  const E* __restrict__ xg = reinterpret_cast<const E*>(a.x);
+  const int wsel = a.widx ? a.widx[b] : 0;
+  const E* __restrict__ wg = reinterpret_cast<const E*>(a.w) + (size_t)wsel * KS * a.Cout_p * a.w_pitch;
+  const long row_base = a.x_row0 + (long)b * a.x_sample_rows + t0 - halo;   // LDS x row 0
+  const int NX = TILE_T + 2 * halo;
+
+  unsigned char* xs = smem;
+  unsigned char* ws = smem + XS_BYTES;
+
+  f32x4 acc[4][NREP];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nslab = a.Cin_p / SLAB;
+  const int per_split = (nslab + a.ksplit - 1) / a.ksplit;
+  const int s_begin = ks * per_split;
+  const int s_end = min(nslab, s_begin + per_split);
+
+  for (int s = s_begin; s < s_end; ++s) {
+    __syncthreads();
+    // ---- stage the input slab: NX rows x 128 bytes
+    for (int idx = tid; idx < NX * 8; idx += 256) {
+      const int r = idx >> 3, c = idx & 7;
+      const long row = row_base + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row >= 0 && row < a.x_rows_limit)
+        v = *reinterpret_cast<const uint4*>(xg + (size_t)row * a.x_pitch + (size_t)s * SLAB + c * PER16);
+      *reinterpret_cast<uint4*>(xs + lds_sw(r, c)) = v;
+    }
+    // ---- stage the weight slab: KS x TILE_CO rows x 128 bytes
+    for (int idx = tid; idx < KS * TILE_CO * 8; idx += 256) {
+      const int r = idx >> 3, c = idx & 7;
+      const int tap = r / TILE_CO, co = r - tap * TILE_CO;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (co0 + co < a.w_rows_limit)
+        v = *reinterpret_cast<const uint4*>(wg + ((size_t)tap * a.Cout_p + co0 + co) * a.w_pitch +
+                                            (size_t)s * SLAB + c * PER16);
+      *reinterpret_cast<uint4*>(ws + lds_sw(r, c)) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int tap = 0; tap < KS; ++tap) {
+        uint4 af[4], bf[NREP];
+        const int xrow = wave_t * 64 + lr + tap * dil;
+        const int wrow = tap * TILE_CO + wave_c * HALF_CO + lr;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          af[m] = *reinterpret_cast<const uint4*>(xs + lds_sw(xrow + m * 16, kk * 4 + lq));
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+          bf[n] = *reinterpret_cast<const uint4*>(ws + lds_sw(wrow + n * 16, kk * 4 + lq));
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af[m], bf[n], acc[m][n]);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ split-K: raw fp32 partials
+  if (a.partial) {
+    float* __restrict__ pp = a.partial + (size_t)ks * a.T * a.Cout_p;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int t = t0 + wave_t * 64 + m * 16 + lq * 4 + r;
+          const int co = co0 + wave_c * HALF_CO + n * 16 + lr;
+          if (t < a.T) pp[(size_t)t * a.Cout_p + co] = acc[m][n][r];
+        }
+    return;
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  if (a.bias) {
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const float bv = a.bias[co0 + wave_c * HALF_CO + n * 16 + lr];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][n][r] += bv;
+    }
+  }
+  float* ep = reinterpret_cast<float*>(smem);
+  float* red = reinterpret_cast<float*>(smem + G::EP_BYTES);
+  const int chunk = tid % G::NCH, rg = tid / G::NCH;
+  const bool active = rg < G::RG;
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  E* __restrict__ yg = reinterpret_cast<E*>(a.y);
+  E* __restrict__ ypre = reinterpret_cast<E*>(a.y_pre);
+  const E* __restrict__ resg = reinterpret_cast<const E*>(a.res);
+  const long out_row0 = a.x_row0 + (long)b * a.x_sample_rows + t0;
+
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();            // main-loop LDS reads (h == 0) / previous half's reads are done
+    if (wave_t == h) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            ep[(m * 16 + lq * 4 + r) * G::STRIDE + wave_c * HALF_CO + n * 16 + lr] = acc[m][n][r];
+    }
+    __syncthreads();
+    if (active) {
+      for (int row = rg; row < EP_ROWS; row += G::RG) {
+        const int t = t0 + h * EP_ROWS + row;
+        if (t >= a.T) break;
+        float4 v = *reinterpret_cast<const float4*>(ep + row * G::STRIDE + chunk * 4);
+        const size_t off = (size_t)(out_row0 + h * EP_ROWS + row) * a.Cout_p + co0 + chunk * 4;
+        if (resg) {
+          const float4 rv = load4(resg + off);
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (a.flags & SDA_EPI_GELU) {
+          if (ypre) store4(ypre + off, v);
+          v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+        }
+        store4(yg + off, v);
+        if (a.stats) {
+          // statistics of the values as stored (rounded to E), so BN normalises what it will read
+          const float4 q = load4(yg + off);
+          ssum[0] += q.x; ssum[1] += q.y; ssum[2] += q.z; ssum[3] += q.w;
+          ssq[0] += q.x * q.x; ssq[1] += q.y * q.y; ssq[2] += q.z * q.z; ssq[3] += q.w * q.w;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[(rg * 2 + 0) * TILE_CO + chunk * 4 + j] = ssum[j];
+        red[(rg * 2 + 1) * TILE_CO + chunk * 4 + j] = ssq[j];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * TILE_CO; i += 256) {
+      const int which = i / TILE_CO, c = i - which * TILE_CO;
+      float s = 0.f;
+      for (int g = 0; g < G::RG; ++g) s += red[(g * 2 + which) * TILE_CO + c];
+      a.stats[((size_t)(b * n_t_tiles + t_tile) * 2 + which) * a.Cout_p + co0 + c] = s;
+    }
+  }
+}
+
+template <typename E, int TILE_CO, int KS>
+static int launch_conv(const sda_conv_args& a, hipStream_t st) {
+  constexpr int lds = conv_lds_bytes<TILE_CO, KS>();
+  static bool attr_done = false;
+  auto kern = conv_gemm_kernel<E, TILE_CO, KS>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds) != hipSuccess) {
+      set_error("conv_gemm: cannot reserve %d bytes of LDS", lds);
+      return -3;
+    }
+    attr_done = true;
+  }
+  const int n_t = (a.T + TILE_T - 1) / TILE_T;
+  const long grid = (long)(a.Cout_p / TILE_CO) * n_t * a.B * a.ksplit;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a, n_t);
+  return check_launch("conv_gemm");
+}
+
+template <typename E>
+static int dispatch_conv(const sda_conv_args& a, hipStream_t st) {
+  const bool k3 = a.KS == 3;
+  if (a.Cout_p % 160 == 0) return k3 ? launch_conv<E, 160, 3>(a, st) : launch_conv<E, 160, 1>(a, st);
+  if (a.Cout_p % 128 == 0) return k3 ? launch_conv<E, 128, 3>(a, st) : launch_conv<E, 128, 1>(a, st);
+  return k3 ? launch_conv<E, 64, 3>(a, st) : launch_conv<E, 64, 1>(a, st);
+}
+
+}  // namespace sda
+
+using namespace sda;
+
+extern "C" int sda_conv_n_t_tiles(int T) { return (T + TILE_T - 1) / TILE_T; }
+
+extern "C" int sda_conv_gemm(const sda_conv_args* a, void* stream) {
+  if (!a || !a->x || !a->w || (!a->y && !a->partial)) { set_error("conv_gemm: null argument"); return -1; }
+  if (a->KS != 1 && a->KS != 3) { set_error("conv_gemm: kernel size %d not supported (1 or 3)", a->KS); return -1; }
+  if (a->dil < 0 || a->dil > PAD) { set_error("conv_gemm: dilation %d outside [0, %d]", a->dil, PAD); return -1; }
+  if (a->Cout_p % 64 || a->Cin_p % 64) { set_error("conv_gemm: channel extents (%d, %d) must be multiples of 64", a->Cin_p, a->Cout_p); return -1; }
+  if (a->x_pitch % 8 || a->w_pitch % 8 || a->x_pitch < a->Cin_p || a->w_pitch < a->Cin_p) { set_error("conv_gemm: bad pitch"); return -1; }
+  if (a->ksplit < 1 || (a->ksplit > 1 && (!a->partial || a->B != 1))) { set_error("conv_gemm: split-K needs partial output and B == 1"); return -1; }
+  if (a->partial && a->ksplit < 1) { set_error("conv_gemm: bad ksplit"); return -1; }
+  if (a->B < 1 || a->T < 1) { set_error("conv_gemm: empty batch"); return -1; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == SDA_F32) return dispatch_conv<float>(*a, st);
+  if (a->dtype == SDA_BF16) return dispatch_conv<uint16_t>(*a, st);
+  set_error("conv_gemm: unknown dtype %d", a->dtype);
+  return -1;
+}

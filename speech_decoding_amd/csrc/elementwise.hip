@@ -1,0 +1,565 @@
+// HBM-bound stages of the path: layout packing, BatchNorm statistics/apply (+GELU), GLU, GELU
+// backward, column sums, slab reduction.  All kernels touch VALID rows only (pad rows stay zero) and
+// move 16 bytes (fp32) / 8-16 bytes (bf16) per lane.  Reductions are two-stage and ordered, so results
+// are bitwise reproducible run to run.
+#include "sd_common.h"
+
+namespace sda {
+
+// ------------------------------------------------------------------------------------------------
+// (B, C, T) fp32  <->  RL rows
+// ------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, E* __restrict__ dst,
+                                                        int C, int T, int Cp) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc, t = t0 + tx;
+    tile[cc][tx] = (c < C && t < T) ? src[((size_t)b * C + c) * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int t = t0 + rr;
+    if (t < T) Elem<E>::st(dst + ((size_t)b * rows_tp(T) + PAD + t) * Cp + c0 + tx, tile[tx][rr]);
+  }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const E* __restrict__ src, float* __restrict__ dst,
+                                                          int C, int T, int Cp) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int t = t0 + rr;
+    tile[rr][tx] = (t < T) ? Elem<E>::ld(src + ((size_t)b * rows_tp(T) + PAD + t) * Cp + c0 + tx) : 0.f;
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc, t = t0 + tx;
+    if (c < C && t < T) dst[((size_t)b * C + c) * T + t] = tile[tx][cc];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-sample sum of squares (loss.py:64-65 norms), two-stage
+// ------------------------------------------------------------------------------------------------
+constexpr int SUMSQ_CHUNKS = 64;
+
+template <typename E>
+__global__ __launch_bounds__(256) void rows_sumsq_kernel(const E* __restrict__ x, float* __restrict__ scratch,
+                                                         long row_elems, long pitch) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const long n4 = row_elems / 4;
+  const long per = (n4 + SUMSQ_CHUNKS - 1) / SUMSQ_CHUNKS;
+  const long beg = ch * per, end = min(n4, beg + per);
+  const E* p = x + (size_t)b * pitch;
+  float s = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    const float4 v = load4(p + i * 4);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) scratch[b * SUMSQ_CHUNKS + ch] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void rows_sumsq_final_kernel(const float* __restrict__ scratch, float* __restrict__ out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s = 0.0;
+  for (int i = 0; i < SUMSQ_CHUNKS; ++i) s += (double)scratch[b * SUMSQ_CHUNKS + i];
+  out[b] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight / vector packing
+// ------------------------------------------------------------------------------------------------
+__device__ inline int glu_unmap(int cop, int Cout, int half, int half_p) {   // packed row -> source row or -1
+  if (half == 0) return cop < Cout ? cop : -1;
+  if (cop < half_p) return cop < half ? cop : -1;
+  const int r = cop - half_p;
+  return r < Cout - half ? half + r : -1;
+}
+__device__ inline int glu_map(int co, int half, int half_p) { return (half == 0 || co < half) ? co : half_p + co - half; }
+
+template <typename E>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, E* __restrict__ dst, int nW, int Cout, int Cin,
+                                        int KS, int Cout_p, int Cin_p, int mode, int half, int half_p) {
+  const size_t total = (size_t)nW * KS * Cout_p * Cin_p;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int co, ci, tap;
+    size_t q = i;
+    if (mode == 0) {
+      ci = q % Cin_p; q /= Cin_p;
+      co = glu_unmap((int)(q % Cout_p), Cout, half, half_p); q /= Cout_p;
+      tap = q % KS; q /= KS;
+    } else {
+      co = glu_unmap((int)(q % Cout_p), Cout, half, half_p); q /= Cout_p;
+      ci = q % Cin_p; q /= Cin_p;
+      tap = KS - 1 - (int)(q % KS); q /= KS;
+    }
+    const int n = (int)q;
+    float v = 0.f;
+    if (co >= 0 && ci < Cin) v = w[(((size_t)n * Cout + co) * Cin + ci) * KS + tap];
+    Elem<E>::st(dst + i, v);
+  }
+}
+
+__global__ void unpack_conv_wgrad_kernel(const float* __restrict__ g, float* __restrict__ dst, int nW, int Cout,
+                                         int Cin, int KS, int Cout_p, int Cin_p, int half, int half_p) {
+  const size_t total = (size_t)nW * Cout * Cin * KS;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t q = i;
+    const int tap = q % KS; q /= KS;
+    const int ci = q % Cin; q /= Cin;
+    const int co = q % Cout; q /= Cout;
+    const int n = (int)q;
+    dst[i] = g[(((size_t)n * KS + tap) * Cout_p + glu_map(co, half, half_p)) * Cin_p + ci];
+  }
+}
+
+__global__ void pack_vector_kernel(const float* __restrict__ v, float* __restrict__ dst, int C, int Cp, int half, int half_p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cp) return;
+  const int c = glu_unmap(i, C, half, half_p);
+  dst[i] = c >= 0 ? v[c] : 0.f;
+}
+__global__ void unpack_vector_kernel(const float* __restrict__ g, float* __restrict__ dst, int C, int half, int half_p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C) dst[i] = g[glu_map(i, half, half_p)];
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm1d: finalize / apply+GELU / backward   (models.py:135,143,158,161)
+// ------------------------------------------------------------------------------------------------
+// Sum partial[k][which][c] over k for the 32 channels of this block: 8 thread groups stride over k,
+// fp64 accumulation, fixed combination order (deterministic).  Result valid for threadIdx.x < 32.
+__device__ inline void block_partial_sums(const float* __restrict__ partial, int n, int Cp, int c, bool two,
+                                          double& s0, double& s1) {
+  __shared__ double sh[2][8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < Cp) {
+    for (int k = ty; k < n; k += 8) {
+      a0 += (double)partial[((size_t)k * 2 + 0) * Cp + c];
+      if (two) a1 += (double)partial[((size_t)k * 2 + 1) * Cp + c];
+    }
+  }
+  sh[0][ty][tx] = a0;
+  sh[1][ty][tx] = a1;
+  __syncthreads();
+  s0 = 0.0; s1 = 0.0;
+  if (ty == 0) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { s0 += sh[0][g][tx]; s1 += sh[1][g][tx]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* mean_o,
+                                   float* rstd_o, float* scale_o, float* shift_o, int C, int Cp, int training) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  double s = 0.0, q = 0.0;
+  if (training) block_partial_sums(partial, ntiles, Cp, c, true, s, q);
+  if (threadIdx.x >= 32 || c >= Cp) return;
+  if (c >= C) { mean_o[c] = 0.f; rstd_o[c] = 0.f; scale_o[c] = 0.f; shift_o[c] = 0.f; return; }
+  double mean, var;
+  if (training) {
+    mean = s / count;
+    var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] * rstd;
+  mean_o[c] = (float)mean;
+  rstd_o[c] = (float)rstd;
+  scale_o[c] = (float)sc;
+  shift_o[c] = (float)((double)beta[c] - mean * sc);
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void bn_gelu_fwd_kernel(const E* __restrict__ x, E* __restrict__ y,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int B, int T, int Cp) {
+  const int nch = Cp / 4;
+  const size_t total = (size_t)B * T * nch;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = i % nch;
+    const size_t vr = i / nch;
+    const int b = vr / T, t = vr - (size_t)b * T;
+    const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
+    const float4 v = load4(x + off);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + ch * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + ch * 4);
+    float4 o;
+    o.x = gelu_f(v.x * sc.x + sh.x); o.y = gelu_f(v.y * sc.y + sh.y);
+    o.z = gelu_f(v.z * sc.z + sh.z); o.w = gelu_f(v.w * sc.w + sh.w);
+    store4(y + off, o);
+  }
+}
+
+constexpr int RED_MAX_BLOCKS = 512;
+
+// Column reductions over valid rows.  MODE 0: sum x (bias grads).  MODE 1: BN+GELU backward sums
+// (dg, dg * xhat) with dg = dy * GELU'(gamma * xhat + beta).
+template <typename E, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ dy, const E* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int C, float* __restrict__ partial, int B, int T, int Cp) {
+  extern __shared__ float red[];
+  const int nch = Cp / 4;
+  const int RG = 256 / nch;
+  const int ch = threadIdx.x % nch, rg = threadIdx.x / nch;
+  const size_t rows = (size_t)B * T;
+  const size_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const size_t r0 = (size_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+  float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  if (rg < RG) {
+    float mu[4], rs[4], ga[4], be[4];
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = ch * 4 + j;
+        mu[j] = mean[c]; rs[j] = rstd[c];
+        ga[j] = c < C ? gamma[c] : 0.f; be[j] = c < C ? beta[c] : 0.f;
+      }
+    }
+    for (size_t r = r0 + rg; r < r1; r += RG) {
+      const int b = r / T, t = r - (size_t)b * T;
+      const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
+      const float4 d = load4(dy + off);
+      const float dv[4] = {d.x, d.y, d.z, d.w};
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0[j] += dv[j];
+      } else {
+        const float4 xv4 = load4(x + off);
+        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[j] - mu[j]) * rs[j];
+          const float dg = dv[j] * gelu_grad_f(ga[j] * xh + be[j]);
+          a0[j] += dg;
+          a1[j] += dg * xh;
+        }
+      }
+    }
+  }
+  if (rg < RG) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[(rg * 2 + 0) * Cp + ch * 4 + j] = a0[j];
+      red[(rg * 2 + 1) * Cp + ch * 4 + j] = a1[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * Cp; i += 256) {
+    const int which = i / Cp, c = i - which * Cp;
+    float s = 0.f;
+    for (int g = 0; g < RG; ++g) s += red[(g * 2 + which) * Cp + c];
+    partial[((size_t)blockIdx.x * 2 + which) * Cp + c] = s;
+  }
+}
+
+// sums[which][c] = sum over blocks (fp64, fixed order)
+__global__ __launch_bounds__(256) void col_reduce_final_kernel(const float* __restrict__ partial, int nblocks,
+                                                               float* __restrict__ out0, float* __restrict__ out1, int Cp) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  double s0, s1;
+  block_partial_sums(partial, nblocks, Cp, c, out1 != nullptr, s0, s1);
+  if (threadIdx.x >= 32 || c >= Cp) return;
+  out0[c] = (float)s0;
+  if (out1) out1[c] = (float)s1;
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restrict__ dy, const E* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int C, const float* __restrict__ dbeta,
+                                                                const float* __restrict__ dgamma, float inv_count,
+                                                                E* __restrict__ dx, int B, int T, int Cp) {
+  const int nch = Cp / 4;
+  const size_t total = (size_t)B * T * nch;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = i % nch;
+    const size_t vr = i / nch;
+    const int b = vr / T, t = vr - (size_t)b * T;
+    const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
+    const float4 d4 = load4(dy + off), x4 = load4(x + off);
+    const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = ch * 4 + j;
+      const float ga = c < C ? gamma[c] : 0.f, be = c < C ? beta[c] : 0.f;
+      const float xh = (xv[j] - mean[c]) * rstd[c];
+      const float dg = dv[j] * gelu_grad_f(ga * xh + be);
+      o[j] = ga * rstd[c] * (dg - dbeta[c] * inv_count - xh * dgamma[c] * inv_count);
+    }
+    store4(dx + off, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GLU (models.py:164) and GELU backward
+// ------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const E* __restrict__ x, E* __restrict__ y, int B, int T, int Ch) {
+  const int nch = Ch / 4;
+  const size_t total = (size_t)B * T * nch;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = i % nch;
+    const size_t vr = i / nch;
+    const int b = vr / T, t = vr - (size_t)b * T;
+    const size_t row = (size_t)b * rows_tp(T) + PAD + t;
+    const float4 a = load4(x + row * 2 * Ch + ch * 4), g = load4(x + row * 2 * Ch + Ch + ch * 4);
+    store4(y + row * Ch + ch * 4, make_float4(a.x * sigmoid_f(g.x), a.y * sigmoid_f(g.y), a.z * sigmoid_f(g.z),
+                                              a.w * sigmoid_f(g.w)));
+  }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const E* __restrict__ x, const E* __restrict__ dy,
+                                                      E* __restrict__ dx, int B, int T, int Ch) {
+  const int nch = Ch / 4;
+  const size_t total = (size_t)B * T * nch;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = i % nch;
+    const size_t vr = i / nch;
+    const int b = vr / T, t = vr - (size_t)b * T;
+    const size_t row = (size_t)b * rows_tp(T) + PAD + t;
+    const float4 a4 = load4(x + row * 2 * Ch + ch * 4), g4 = load4(x + row * 2 * Ch + Ch + ch * 4);
+    const float4 d4 = load4(dy + row * Ch + ch * 4);
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w};
+    float da[4], dg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float s = sigmoid_f(g[j]);
+      da[j] = d[j] * s;
+      dg[j] = d[j] * a[j] * s * (1.f - s);
+    }
+    store4(dx + row * 2 * Ch + ch * 4, make_float4(da[0], da[1], da[2], da[3]));
+    store4(dx + row * 2 * Ch + Ch + ch * 4, make_float4(dg[0], dg[1], dg[2], dg[3]));
+  }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const E* __restrict__ u, const E* __restrict__ dz,
+                                                       E* __restrict__ du, int B, int T, int Cp) {
+  const int nch = Cp / 4;
+  const size_t total = (size_t)B * T * nch;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = i % nch;
+    const size_t vr = i / nch;
+    const int b = vr / T, t = vr - (size_t)b * T;
+    const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
+    const float4 uv = load4(u + off), d = load4(dz + off);
+    store4(du + off, make_float4(d.x * gelu_grad_f(uv.x), d.y * gelu_grad_f(uv.y), d.z * gelu_grad_f(uv.z),
+                                 d.w * gelu_grad_f(uv.w)));
+  }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ src, float* __restrict__ dst, int nslabs, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nslabs; ++k) s += src[(size_t)k * n + i];
+    dst[i] = s;
+  }
+}
+
+static inline int ew_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+static int red_blocks(int B, int T) {
+  long rows = (long)B * T;
+  long nb = (rows + 63) / 64;
+  if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+}  // namespace sda
+
+using namespace sda;
+
+#define SDA_DISPATCH(dtype, CALL)                                   \
+  do {                                                              \
+    if ((dtype) == SDA_F32) { using E = float; CALL; }              \
+    else if ((dtype) == SDA_BF16) { using E = uint16_t; CALL; }     \
+    else { set_error("unknown dtype %d", (int)(dtype)); return -1; } \
+  } while (0)
+
+extern "C" int sda_pack_rows(const float* src, void* dst, int B, int C, int T, int Cp, int dtype, void* stream) {
+  if (!src || !dst || Cp % 64 || C > Cp || B < 1) { set_error("pack_rows: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((T + 63) / 64, Cp / 64, B);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_rows_kernel<E>, grid, dim3(256), 0, st, src, (E*)dst, C, T, Cp));
+  return check_launch("pack_rows");
+}
+
+extern "C" int sda_unpack_rows(const void* src, float* dst, int B, int C, int T, int Cp, int dtype, void* stream) {
+  if (!src || !dst || Cp % 64 || C > Cp || B < 1) { set_error("unpack_rows: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((T + 63) / 64, Cp / 64, B);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(unpack_rows_kernel<E>, grid, dim3(256), 0, st, (const E*)src, dst, C, T, Cp));
+  return check_launch("unpack_rows");
+}
+
+extern "C" int sda_rows_sumsq(const void* x, float* out, float* scratch, int B, long row_elems, long pitch,
+                              int dtype, void* stream) {
+  if (!x || !out || !scratch || row_elems % 4 || pitch % 4 || B < 1) { set_error("rows_sumsq: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(rows_sumsq_kernel<E>, dim3(SUMSQ_CHUNKS, B), dim3(256), 0, st,
+                                         (const E*)x, scratch, row_elems, pitch));
+  hipLaunchKernelGGL(rows_sumsq_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, scratch, out, B);
+  return check_launch("rows_sumsq");
+}
+
+extern "C" int sda_pack_conv_weight(const float* w, void* dst, int nW, int Cout, int Cin, int KS, int Cout_p,
+                                    int Cin_p, int mode, int glu_half, int glu_half_p, int dtype, void* stream) {
+  if (!w || !dst || nW < 1 || Cout > Cout_p || Cin > Cin_p || (mode != 0 && mode != 1)) { set_error("pack_conv_weight: bad arguments"); return -1; }
+  if (glu_half && (glu_half_p < glu_half || glu_half_p + (Cout - glu_half) > Cout_p)) { set_error("pack_conv_weight: bad GLU split"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = (size_t)nW * KS * Cout_p * Cin_p;
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_conv_weight_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, st, w,
+                                         (E*)dst, nW, Cout, Cin, KS, Cout_p, Cin_p, mode, glu_half, glu_half_p));
+  return check_launch("pack_conv_weight");
+}
+
+extern "C" int sda_unpack_conv_wgrad(const float* g, float* dst, int nW, int Cout, int Cin, int KS, int Cout_p,
+                                     int Cin_p, int glu_half, int glu_half_p, void* stream) {
+  if (!g || !dst) { set_error("unpack_conv_wgrad: null"); return -1; }
+  const size_t total = (size_t)nW * Cout * Cin * KS;
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, g, dst, nW,
+                     Cout, Cin, KS, Cout_p, Cin_p, glu_half, glu_half_p);
+  return check_launch("unpack_conv_wgrad");
+}
+
+extern "C" int sda_pack_vector(const float* v, float* dst, int C, int Cp, int glu_half, int glu_half_p, void* stream) {
+  if (!v || !dst || C > Cp) { set_error("pack_vector: bad arguments"); return -1; }
+  hipLaunchKernelGGL(pack_vector_kernel, dim3((Cp + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, dst, C, Cp,
+                     glu_half, glu_half_p);
+  return check_launch("pack_vector");
+}
+
+extern "C" int sda_unpack_vector(const float* g, float* dst, int C, int Cp, int glu_half, int glu_half_p, void* stream) {
+  if (!g || !dst || C > Cp) { set_error("unpack_vector: bad arguments"); return -1; }
+  hipLaunchKernelGGL(unpack_vector_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, dst, C,
+                     glu_half, glu_half_p);
+  return check_launch("unpack_vector");
+}
+
+extern "C" int sda_bn_finalize(const float* partial, int ntiles, double count, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                               float* rstd, float* scale, float* shift, int C, int Cp, int training, void* stream) {
+  if (!gamma || !beta || !mean || !rstd || !scale || !shift || C > Cp) { set_error("bn_finalize: bad arguments"); return -1; }
+  if (training && (!partial || ntiles < 1 || count < 1.0)) { set_error("bn_finalize: training mode needs partial statistics"); return -1; }
+  if (!training && (!running_mean || !running_var)) { set_error("bn_finalize: eval mode needs running statistics"); return -1; }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, ntiles, count,
+                     gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, C, Cp, training);
+  return check_launch("bn_finalize");
+}
+
+extern "C" int sda_bn_gelu_forward(const void* x, void* y, const float* scale, const float* shift, int B, int T,
+                                   int Cp, int dtype, void* stream) {
+  if (!x || !y || !scale || !shift || Cp % 64) { set_error("bn_gelu_forward: bad arguments"); return -1; }
+  const size_t total = (size_t)B * T * (Cp / 4);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_fwd_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                         (const E*)x, (E*)y, scale, shift, B, T, Cp));
+  return check_launch("bn_gelu_forward");
+}
+
+extern "C" int sda_bn_bwd_max_blocks(void) { return RED_MAX_BLOCKS; }
+
+extern "C" int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const float* mean, const float* rstd,
+                                           const float* gamma, const float* beta, int C, float* partial, float* dgamma,
+                                           float* dbeta, int B, int T, int Cp, int dtype, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !beta || !partial || !dgamma || !dbeta || Cp % 64 || Cp > 1024) {
+    set_error("bn_gelu_backward_reduce: bad arguments"); return -1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = red_blocks(B, T);
+  const int RG = 256 / (Cp / 4);
+  const size_t lds = (size_t)RG * 2 * Cp * sizeof(float);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL((col_reduce_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)dy,
+                                         (const E*)x, mean, rstd, gamma, beta, C, partial, B, T, Cp));
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 31) / 32), dim3(256), 0, st, partial, nb, dbeta, dgamma, Cp);
+  return check_launch("bn_gelu_backward_reduce");
+}
+
+extern "C" int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean, const float* rstd,
+                                          const float* gamma, const float* beta, int C, const float* dgamma,
+                                          const float* dbeta, double count, void* dx, int B, int T, int Cp, int dtype,
+                                          void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !dx || Cp % 64 || count < 1.0) {
+    set_error("bn_gelu_backward_apply: bad arguments"); return -1;
+  }
+  const size_t total = (size_t)B * T * (Cp / 4);
+  const float inv_count = (float)(1.0 / count);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(ew_grid(total)), dim3(256), 0,
+                                         (hipStream_t)stream, (const E*)dy, (const E*)x, mean, rstd, gamma, beta, C,
+                                         dbeta, dgamma, inv_count, (E*)dx, B, T, Cp));
+  return check_launch("bn_gelu_backward_apply");
+}
+
+extern "C" int sda_colsum(const void* x, float* out, float* scratch, int B, int T, int Cp, int dtype, void* stream) {
+  if (!x || !out || !scratch || Cp % 64 || Cp > 1024) { set_error("colsum: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = red_blocks(B, T);
+  const int RG = 256 / (Cp / 4);
+  const size_t lds = (size_t)RG * 2 * Cp * sizeof(float);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL((col_reduce_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)x,
+                                         (const E*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, B, T, Cp));
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 31) / 32), dim3(256), 0, st, scratch, nb, out, (float*)nullptr, Cp);
+  return check_launch("colsum");
+}
+
+extern "C" int sda_reduce_scratch_floats(int Cp) { return RED_MAX_BLOCKS * 2 * Cp; }
+
+extern "C" int sda_glu_forward(const void* x, void* y, int B, int T, int Ch, int dtype, void* stream) {
+  if (!x || !y || Ch % 64) { set_error("glu_forward: bad arguments"); return -1; }
+  const size_t total = (size_t)B * T * (Ch / 4);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(glu_fwd_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                         (const E*)x, (E*)y, B, T, Ch));
+  return check_launch("glu_forward");
+}
+
+extern "C" int sda_glu_backward(const void* x, const void* dy, void* dx, int B, int T, int Ch, int dtype, void* stream) {
+  if (!x || !dy || !dx || Ch % 64) { set_error("glu_backward: bad arguments"); return -1; }
+  const size_t total = (size_t)B * T * (Ch / 4);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(glu_bwd_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                         (const E*)x, (const E*)dy, (E*)dx, B, T, Ch));
+  return check_launch("glu_backward");
+}
+
+extern "C" int sda_gelu_backward(const void* u, const void* dz, void* du, int B, int T, int Cp, int dtype, void* stream) {
+  if (!u || !dz || !du || Cp % 64) { set_error("gelu_backward: bad arguments"); return -1; }
+  const size_t total = (size_t)B * T * (Cp / 4);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(gelu_bwd_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                         (const E*)u, (const E*)dz, (E*)du, B, T, Cp));
+  return check_launch("gelu_backward");
+}
+
+extern "C" int sda_reduce_slabs(const float* src, float* dst, int nslabs, long n, void* stream) {
+  if (!src || !dst || nslabs < 1 || n < 1) { set_error("reduce_slabs: bad arguments"); return -1; }
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, src, dst, nslabs, n);
+  return check_launch("reduce_slabs");
+}

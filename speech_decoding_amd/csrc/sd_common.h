@@ -1,0 +1,111 @@
+// Common device/host helpers for the gfx950 kernels of the contrastive training path.
+// CDNA4 only: 64-lane wavefronts, MFMA 16x16 tiles, 128-byte swizzled LDS rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sd_amd.h"
+
+namespace sda {
+
+// ------------------------------------------------------------------------------------------
+// Activation "row layout" (RL).  A tensor (B, C, T) lives as rows of Cp channels (channels-last):
+//   row(b, t) = b * Tp + PAD + t,   Tp = T + PAD,   PAD = 16 (= the largest dilation)
+// The PAD rows in front of every sample (and behind the last one) are always zero, so a dilated tap
+// that leaves [0, T) reads zeros without any masking.  Channel padding (Cp - C) is zero as well.
+// R_alloc adds slack behind the last sample so that a 128-row tile may overrun harmlessly.
+// ------------------------------------------------------------------------------------------
+constexpr int PAD = SDA_ROW_PAD;
+constexpr int TILE_T = 128;               // output rows per workgroup (conv_gemm)
+constexpr int ROW_SLACK = TILE_T + 2 * PAD;
+
+__host__ __device__ inline int rows_tp(int T) { return T + PAD; }
+__host__ __device__ inline long rows_alloc(int B, int T) { return (long)B * rows_tp(T) + PAD + ROW_SLACK; }
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// bf16 <-> f32 (round to nearest even; NaN stays NaN through the compiler's cvt)
+__device__ inline float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ inline uint16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<uint16_t*>(&b);
+}
+
+// Element traits: E = float (exact fp32 path on the f32 MFMA) or uint16_t (bf16 storage).
+template <typename E> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int PER16 = 4;      // elements per 16-byte chunk
+  static constexpr int SLAB = 32;      // elements per 128-byte LDS row
+  __device__ static float ld(const float* p) { return *p; }
+  __device__ static void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<uint16_t> {
+  static constexpr int PER16 = 8;
+  static constexpr int SLAB = 64;
+  __device__ static float ld(const uint16_t* p) { return bf2f(*p); }
+  __device__ static void st(uint16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 4 consecutive elements <-> float4 (16-byte fp32 / 8-byte bf16 accesses)
+__device__ inline float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline float4 load4(const uint16_t* p) {
+  uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ inline void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ inline void store4(uint16_t* p, float4 v) {
+  uint2 u;
+  u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+  u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+// Byte offset of 16-byte chunk `chunk` (0..7) of 128-byte LDS row `row`, XOR-swizzled so that 16
+// lanes reading the same chunk of 16 consecutive rows (the MFMA operand pattern) hit 16 distinct
+// 16-byte slots of the 256-byte bank row.
+__device__ inline int lds_sw(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
+
+// One 64-byte K-step (4 lane groups x 16 bytes) of MFMA work on a 16x16 output tile.
+// bf16: one v_mfma_f32_16x16x32_bf16.  fp32: four v_mfma_f32_16x16x4_f32; lane group g supplies
+// k = 4g + j at step j for BOTH operands, so the contraction covers the same 16 k values.
+template <typename E> __device__ inline f32x4 mma16(const uint4& a, const uint4& b, f32x4 c);
+template <> __device__ inline f32x4 mma16<uint16_t>(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const s16x8*>(&a),
+                                                 *reinterpret_cast<const s16x8*>(&b), c, 0, 0, 0);
+}
+template <> __device__ inline f32x4 mma16<float>(const uint4& a, const uint4& b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  return c;
+}
+
+// exact (erf) GELU and its derivative — F.gelu default (models.py:158,161,194,195)
+__device__ inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ inline float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ inline float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// host-side error plumbing (capi.hip)
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+}  // namespace sda

@@ -1,0 +1,235 @@
+// wgrad_gemm — contraction over ROWS (time) of two channels-last tensors on MFMA:
+//     g[seg][tap][co][ci] = sum_{b in seg} sum_t dy[b, t, co] * x[b, t + (tap - KS/2) * dil, ci]
+// Reference ops this replaces: the weight gradients autograd derives for every nn.Conv1d on the path
+// (models.py:97-109,128-150,188-189), for SpatialAttention's mix (models.py:65) and — in typed-output
+// mode — the embedding gradient of the similarity matmul (loss.py:68): dZ = G^T Y - diag(r) Z.
+//
+// Both operands are contracted over their slow (row) index, so the MFMA fragments are TRANSPOSED reads
+// of row-major LDS images: bf16 uses ds_read_b64_tr_b16 (two per 16x16x32 operand; lane group g takes
+// rows {4g..4g+3} and {16+4g..16+4g+3} for BOTH operands, which keeps a 32-lane half on 8 consecutive
+// rows = 8 distinct 32-byte bank segments with a row stride = 32 (mod 64) bytes); fp32 uses ds_read_b32
+// with row stride = 16 (mod 32) words.  One workgroup = 4 waves (2 x 2) owns a TILE_M x 64 output tile for
+// all KS taps and streams its segment's samples in 64-row chunks; the three taps read the same staged x
+// image at row offsets tap*dil.  Segments make the K split explicit: per-subject weight gradients use one
+// segment per subject (final result, no reduction), shared weights use ~CU-count segments + reduce_slabs.
+#include "sd_common.h"
+
+namespace sda {
+
+constexpr int WG_KT = 64;       // rows (time steps) per staged chunk
+constexpr int WG_TN = 64;       // ci columns per workgroup
+
+template <typename E> struct WImg;      // row stride (bytes) of an LDS image holding `cols` elements per row
+template <> struct WImg<uint16_t> { static __host__ __device__ constexpr int stride(int cols) { return cols * 2 + 32; } };
+template <> struct WImg<float> { static __host__ __device__ constexpr int stride(int cols) { return cols * 4 + 64; } };
+
+// transposed MFMA operand: 16 columns starting at col0, 32 (bf16) / 16 (fp32) rows starting at row0
+__device__ inline uint4 tr_operand_bf16(const unsigned char* img, int stride, int row0, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const unsigned char* a0 = img + (row0 + 4 * g + q) * stride + (col0 + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * stride));
+  uint4 r;
+  r.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+  r.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+  r.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+  r.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+  return r;
+}
+// fp32: element j of the lane = row (row0 + 4*j + g)... any bijection works as long as A and B agree
+__device__ inline uint4 tr_operand_f32(const unsigned char* img, int stride, int row0, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const unsigned char* a0 = img + (row0 + g) * stride + (col0 + i) * 4;
+  uint4 r;
+  r.x = *reinterpret_cast<const uint32_t*>(a0);
+  r.y = *reinterpret_cast<const uint32_t*>(a0 + 4 * stride);
+  r.z = *reinterpret_cast<const uint32_t*>(a0 + 8 * stride);
+  r.w = *reinterpret_cast<const uint32_t*>(a0 + 12 * stride);
+  return r;
+}
+template <typename E> __device__ inline uint4 tr_operand(const unsigned char* img, int stride, int row0, int col0, int lane);
+template <> __device__ inline uint4 tr_operand<uint16_t>(const unsigned char* img, int stride, int row0, int col0, int lane) {
+  return tr_operand_bf16(img, stride, row0, col0, lane);
+}
+template <> __device__ inline uint4 tr_operand<float>(const unsigned char* img, int stride, int row0, int col0, int lane) {
+  return tr_operand_f32(img, stride, row0, col0, lane);
+}
+
+template <typename E, int TILE_M, int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int PER16 = Elem<E>::PER16;
+  constexpr int KSTEP = (sizeof(E) == 2) ? 32 : 16;        // rows consumed per mma16
+  constexpr int MREP = TILE_M / 32;                         // 16-row m tiles per wave (wave tile = TILE_M/2 x 32)
+  constexpr int DY_STRIDE = WImg<E>::stride(TILE_M);
+  constexpr int X_STRIDE = WImg<E>::stride(WG_TN);
+  constexpr int DY_BYTES = WG_KT * DY_STRIDE;
+  constexpr int M_CHUNKS = TILE_M / PER16, N_CHUNKS = WG_TN / PER16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wave_m = wid >> 1, wave_n = wid & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int n_n = a.Cin_p / WG_TN, n_m = a.Cout_p / TILE_M;
+  const int n_tile = bid % n_n; bid /= n_n;
+  const int m_tile = bid % n_m; bid /= n_m;
+  const int seg = bid;
+  const int co0 = m_tile * TILE_M, ci0 = n_tile * WG_TN;
+  const int halo = (KS == 3) ? a.dil : 0;
+  const int XR = WG_KT + 2 * halo;
+
+  unsigned char* dys = smem;
+  unsigned char* xs = smem + DY_BYTES;
+
+  f32x4 acc[KS][MREP][2];
+#pragma unroll
+  for (int k = 0; k < KS; ++k)
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) { acc[k][m][0] = f32x4{0, 0, 0, 0}; acc[k][m][1] = f32x4{0, 0, 0, 0}; }
+
+  const E* __restrict__ dyg = reinterpret_cast<const E*>(a.dy);
+  const E* __restrict__ xg = reinterpret_cast<const E*>(a.x);
+  const int s_beg = a.seg_start ? a.seg_start[seg] : 0;
+  const int s_end = a.seg_start ? a.seg_start[seg + 1] : a.B;
+
+  for (int si = s_beg; si < s_end; ++si) {
+    const int b = a.perm ? a.perm[si] : si;
+    const long srow = a.row0 + (long)b * a.sample_rows;
+    for (int t0 = 0; t0 < a.T; t0 += WG_KT) {
+      __syncthreads();
+      for (int idx = tid; idx < WG_KT * M_CHUNKS; idx += 256) {
+        const int r = idx / M_CHUNKS, c = idx - r * M_CHUNKS;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t0 + r < a.T)
+          v = *reinterpret_cast<const uint4*>(dyg + (size_t)(srow + t0 + r) * a.dy_pitch + co0 + c * PER16);
+        *reinterpret_cast<uint4*>(dys + r * DY_STRIDE + c * 16) = v;
+      }
+      for (int idx = tid; idx < XR * N_CHUNKS; idx += 256) {
+        const int r = idx / N_CHUNKS, c = idx - r * N_CHUNKS;
+        const long row = srow + t0 - halo + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row >= 0 && row < a.rows_limit)
+          v = *reinterpret_cast<const uint4*>(xg + (size_t)row * a.x_pitch + ci0 + c * PER16);
+        *reinterpret_cast<uint4*>(xs + r * X_STRIDE + c * 16) = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < WG_KT / KSTEP; ++kk) {
+        uint4 af[MREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+          af[m] = tr_operand<E>(dys, DY_STRIDE, kk * KSTEP, wave_m * (TILE_M / 2) + m * 16, lane);
+#pragma unroll
+        for (int tap = 0; tap < KS; ++tap) {
+          uint4 bf[2];
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            bf[n] = tr_operand<E>(xs, X_STRIDE, kk * KSTEP + tap * a.dil, wave_n * 32 + n * 16, lane);
+#pragma unroll
+          for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[tap][m][n] = mma16<E>(af[m], bf[n], acc[tap][m][n]);
+        }
+      }
+    }
+  }
+
+  if (!a.out_e) {
+    float* __restrict__ gp = a.g + (size_t)seg * KS * a.Cout_p * a.Cin_p;
+#pragma unroll
+    for (int tap = 0; tap < KS; ++tap)
+#pragma unroll
+      for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wave_m * (TILE_M / 2) + m * 16 + lq * 4 + r;
+            const int ci = ci0 + wave_n * 32 + n * 16 + lr;
+            gp[((size_t)tap * a.Cout_p + co) * a.Cin_p + ci] = acc[tap][m][n][r];
+          }
+    return;
+  }
+
+  // typed output through LDS: out[co][ci] = acc - rscale[co] * sub[co][ci]   (KS == 1)
+  constexpr int EP_STRIDE = WG_TN + 4;
+  float* ep = reinterpret_cast<float*>(smem);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < MREP; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ep[(wave_m * (TILE_M / 2) + m * 16 + lq * 4 + r) * EP_STRIDE + wave_n * 32 + n * 16 + lr] = acc[0][m][n][r];
+  __syncthreads();
+  E* __restrict__ og = reinterpret_cast<E*>(a.out_e);
+  const E* __restrict__ sg = reinterpret_cast<const E*>(a.sub);
+  for (int idx = tid; idx < TILE_M * (WG_TN / 4); idx += 256) {
+    const int row = idx / (WG_TN / 4), c4 = idx - row * (WG_TN / 4);
+    const int co = co0 + row;
+    if (co >= a.co_valid) continue;
+    float4 v = *reinterpret_cast<const float4*>(ep + row * EP_STRIDE + c4 * 4);
+    const size_t off = (size_t)co * a.out_pitch + ci0 + c4 * 4;
+    if (sg) {
+      const float rs = a.rscale[co];
+      const float4 s = load4(sg + off);
+      v.x -= rs * s.x; v.y -= rs * s.y; v.z -= rs * s.z; v.w -= rs * s.w;
+    }
+    store4(og + off, v);
+  }
+}
+
+template <int TILE_M, int KS, typename E> constexpr int wgrad_lds_bytes() {
+  constexpr int main_b = WG_KT * WImg<E>::stride(TILE_M) + (WG_KT + 2 * PAD) * WImg<E>::stride(WG_TN);
+  constexpr int epi_b = TILE_M * (WG_TN + 4) * 4;
+  return main_b > epi_b ? main_b : epi_b;
+}
+
+template <typename E, int TILE_M, int KS>
+static int launch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
+  constexpr int lds = wgrad_lds_bytes<TILE_M, KS, E>();
+  static bool attr_done = false;
+  auto kern = wgrad_gemm_kernel<E, TILE_M, KS>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds) != hipSuccess) {
+      set_error("wgrad_gemm: cannot reserve %d bytes of LDS", lds);
+      return -3;
+    }
+    attr_done = true;
+  }
+  const long grid = (long)(a.Cin_p / WG_TN) * (a.Cout_p / TILE_M) * a.nseg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
+  return check_launch("wgrad_gemm");
+}
+
+template <typename E>
+static int dispatch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
+  const bool k3 = a.KS == 3;
+  if (a.Cout_p % 160 == 0) return k3 ? launch_wgrad<E, 160, 3>(a, st) : launch_wgrad<E, 160, 1>(a, st);
+  if (a.Cout_p % 128 == 0) return k3 ? launch_wgrad<E, 128, 3>(a, st) : launch_wgrad<E, 128, 1>(a, st);
+  return k3 ? launch_wgrad<E, 64, 3>(a, st) : launch_wgrad<E, 64, 1>(a, st);
+}
+
+}  // namespace sda
+
+using namespace sda;
+
+extern "C" int sda_wgrad_gemm(const sda_wgrad_args* a, void* stream) {
+  if (!a || !a->dy || !a->x || (!a->g && !a->out_e)) { set_error("wgrad_gemm: null argument"); return -1; }
+  if (a->KS != 1 && a->KS != 3) { set_error("wgrad_gemm: kernel size %d not supported", a->KS); return -1; }
+  if (a->dil < 0 || a->dil > PAD) { set_error("wgrad_gemm: dilation %d outside [0, %d]", a->dil, PAD); return -1; }
+  if (a->Cout_p % 64 || a->Cin_p % 64) { set_error("wgrad_gemm: channel extents must be multiples of 64"); return -1; }
+  if (a->dy_pitch % 8 || a->x_pitch % 8) { set_error("wgrad_gemm: pitches must be multiples of 8 elements"); return -1; }
+  if (a->nseg < 1 || a->B < 1 || a->T < 1) { set_error("wgrad_gemm: empty problem"); return -1; }
+  if (a->out_e && (a->KS != 1 || a->nseg != 1 || a->out_pitch % 8)) { set_error("wgrad_gemm: typed output needs KS == 1, nseg == 1"); return -1; }
+  if (a->out_e && a->sub && !a->rscale) { set_error("wgrad_gemm: sub needs rscale"); return -1; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == SDA_F32) return dispatch_wgrad<float>(*a, st);
+  if (a->dtype == SDA_BF16) return dispatch_wgrad<uint16_t>(*a, st);
+  set_error("wgrad_gemm: unknown dtype %d", a->dtype);
+  return -1;
+}

@@ -1,0 +1,349 @@
+"""Host-side orchestration of the HIP kernels for one encoder forward / backward.
+
+Mirrors the data flow of the reference's `BrainEncoder.forward` (models.py:191-196) and of the
+backward pass autograd derives from it, but every stage is a libsdamd.so kernel launched on the
+current HIP stream over channels-last "row layout" buffers that stay resident in HBM between
+forward and backward.  torch supplies memory and streams only.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+
+
+def block_dilations(k: int):
+    """models.py:133,141,149"""
+    return 2 ** ((2 * k) % 5), 2 ** ((2 * k + 1) % 5), 2
+
+
+@dataclass
+class EncoderDims:
+    C: int
+    S: int
+    D1: int
+    D2: int
+    F: int
+    K: int
+
+    @property
+    def Cp(self): return L.pad_channels(self.C)
+    @property
+    def D1p(self): return L.pad_channels(self.D1)
+    @property
+    def D2p(self): return L.pad_channels(self.D2)
+    @property
+    def F1(self): return 2 * self.D2
+    @property
+    def F1p(self): return L.pad_channels(2 * self.D2)
+    @property
+    def Fp(self): return L.pad_channels(self.F)
+
+
+@dataclass
+class EncoderCtx:
+    """Everything the backward needs; buffers are owned by the engine's workspace."""
+    B: int
+    T: int
+    gen: int
+    training: bool
+    bufs: Dict[str, torch.Tensor] = field(default_factory=dict)
+    packed: Dict[str, torch.Tensor] = field(default_factory=dict)
+    bn: Dict[str, tuple] = field(default_factory=dict)
+    mask: Optional[torch.Tensor] = None
+    widx: Optional[torch.Tensor] = None
+    subj_perm: Optional[torch.Tensor] = None
+    subj_seg: Optional[torch.Tensor] = None
+    W_sa: Optional[torch.Tensor] = None
+
+
+class EncoderEngine:
+    def __init__(self, dims: EncoderDims, dtype: torch.dtype = torch.float32, group=None):
+        L.load()                          # fail loudly if the HIP extension is missing
+        self.d = dims
+        self.dtype = dtype
+        self.group = group                # torch.distributed group for synchronised BatchNorm statistics
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._seg_cache: Dict[tuple, tuple] = {}
+        self._gen = 0
+        self.reuse_workspace = True
+
+    @property
+    def world(self) -> int:
+        if self.group is None:
+            return 1
+        import torch.distributed as dist
+        return dist.get_world_size(self.group)
+
+    def _allreduce(self, t: torch.Tensor):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ------------------------------------------------------------------ workspace
+    def _rows(self, name: str, B: int, T: int, Cp: int, device, space: str) -> torch.Tensor:
+        key = (space, name, B, T, Cp, self.dtype, str(device))
+        if self.reuse_workspace and key in self._ws:
+            return self._ws[key]
+        buf = ops.new_rows(B, T, Cp, self.dtype, device)
+        if self.reuse_workspace:
+            self._ws[key] = buf
+        return buf
+
+    def release_workspace(self):
+        self._ws.clear()
+
+    def _uniform_segments(self, B: int, ntiles: int, device):
+        nseg = int(max(1, min(B, round(256 / max(1, ntiles)))))
+        key = (B, nseg, str(device))
+        if key not in self._seg_cache:
+            edges = np.floor(np.linspace(0, B, nseg + 1)).astype(np.int32)
+            self._seg_cache[key] = (torch.arange(B, dtype=torch.int32, device=device),
+                                    torch.from_numpy(edges).to(device))
+        perm, seg = self._seg_cache[key]
+        return perm, seg, nseg
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, P: Dict[str, torch.Tensor], X: torch.Tensor, subject_idxs, *, training: bool,
+                mask: Optional[torch.Tensor], need_grad: bool, momentum: float = 0.1, eps: float = 1e-5) -> EncoderCtx:
+        d, dt = self.d, self.dtype
+        B, Cc, T = X.shape
+        assert Cc == d.C, f"expected {d.C} channels, got {Cc}"          # models.py:78
+        dev = X.device
+        self._gen += 1
+        space = "train" if need_grad else "eval"
+        ctx = EncoderCtx(B=B, T=T, gen=self._gen, training=training)
+        bufs, pk = ctx.bufs, ctx.packed
+
+        def rows(name, Cp):
+            if not need_grad:            # inference: two ping-pong buffers per width are enough
+                name = f"pp{rows.flip.setdefault(Cp, 0) % 3}"
+                rows.flip[Cp] += 1
+            t = self._rows(name, B, T, Cp, dev, space)
+            return t
+        rows.flip = {}
+
+        # subject indices: CPU int tensor in the reference (train.py:189); validate like ModuleList indexing
+        sidx = torch.as_tensor(subject_idxs).detach().to("cpu").to(torch.int64).numpy()
+        if sidx.shape != (B,):
+            raise ValueError("subject_idxs must have shape (B,)")
+        if (sidx < 0).any() or (sidx >= d.S).any():
+            raise IndexError("subject index out of range")                # ModuleList semantics, models.py:115
+        ctx.widx = torch.from_numpy(sidx.astype(np.int32)).to(dev, non_blocking=True)
+        if need_grad:
+            order = np.argsort(sidx, kind="stable").astype(np.int32)
+            seg = np.searchsorted(sidx[order], np.arange(d.S + 1)).astype(np.int32)
+            ctx.subj_perm = torch.from_numpy(order).to(dev, non_blocking=True)
+            ctx.subj_seg = torch.from_numpy(seg).to(dev, non_blocking=True)
+        ctx.mask = mask
+
+        # ---- operand packing (fp32 master weights -> compute dtype, K-contiguous, zero padded)
+        def packw(key, w, Cout_p, Cin_p, **kw):
+            pk[key] = ops.pack_conv_weight(w, Cout_p, Cin_p, dt, **kw)
+            return pk[key]
+
+        # ---- SubjectBlock (models.py:111-117)
+        Xt = rows("Xt", d.Cp)
+        ops.pack_rows(X, Xt)
+        bufs["Xt"] = Xt
+        W_sa, Wp = ops.sa_weights_forward(P["z"], P["cos"], P["sin"], mask, d.D1p, d.Cp, dt)
+        ctx.W_sa = W_sa
+        h_sa = ops.conv_gemm(Xt, Wp, rows("h_sa", d.D1p), B=B, T=T, KS=1, dil=0, alg_dims=(d.C, d.D1))
+        bufs["h_sa"] = h_sa
+        w = packw("sb_w", P["sb_w"], d.D1p, d.D1p)
+        h_c = ops.conv_gemm(h_sa, w, rows("h_c", d.D1p), B=B, T=T, KS=1, dil=0, bias=ops.pack_vector(P["sb_b"], d.D1p),
+                            alg_dims=(d.D1, d.D1))
+        bufs["h_c"] = h_c
+        w = packw("subj_w", P["subj_w"], d.D1p, d.D1p)
+        x = ops.conv_gemm(h_c, w, rows("x0", d.D1p), B=B, T=T, KS=1, dil=0, widx=ctx.widx, alg_dims=(d.D1, d.D1))
+        bufs["x0"] = x
+
+        # ---- 5 ConvBlocks (models.py:152-166)
+        ntile = B * ops.n_t_tiles(T)
+        world = self.world
+        count = float(B) * T * world            # BatchNorm statistics span the GLOBAL batch under data parallelism
+        for k in range(5):
+            cin_p = d.D1p if k == 0 else d.D2p
+            dil = block_dilations(k)
+            for j in (0, 1):
+                alg = (d.D1 if (k == 0 and j == 0) else d.D2, d.D2)
+                pre = f"b{k}.c{j}"
+                w = packw(pre + "w", P[pre + "w"], d.D2p, cin_p if j == 0 else d.D2p)
+                bias = ops.pack_vector(P[pre + "b"], d.D2p)
+                res = x if (j == 1 or k > 0) else None
+                h = rows(f"b{k}.h{j}", d.D2p)
+                bnp = f"b{k}.bn{j}"
+                if training:
+                    stats = torch.empty((ntile, 2, d.D2p), dtype=torch.float32, device=dev)
+                    ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, stats=stats, alg_dims=alg)
+                    nt = ntile
+                    if world > 1:                # one 2*Cp-float all-reduce per BatchNorm
+                        stats = ops.reduce_slabs(stats).reshape(1, 2, d.D2p)
+                        self._allreduce(stats)
+                        nt = 1
+                    mean, rstd, scale, shift = ops.bn_finalize(stats, nt, count, P[bnp + "w"], P[bnp + "b"],
+                                                               P[bnp + "rm"], P[bnp + "rv"], d.D2p, True, eps, momentum)
+                else:
+                    ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, alg_dims=alg)
+                    mean, rstd, scale, shift = ops.bn_finalize(None, 0, count, P[bnp + "w"], P[bnp + "b"],
+                                                               P[bnp + "rm"], P[bnp + "rv"], d.D2p, False, eps, momentum)
+                ctx.bn[bnp] = (mean, rstd)
+                a = ops.bn_gelu_forward(h, rows(f"b{k}.a{j}", d.D2p), scale, shift, B, T)
+                bufs[f"b{k}.h{j}"], bufs[f"b{k}.a{j}"] = h, a
+                x = a
+            w = packw(f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, glu_half=d.D2, glu_half_p=d.D2p)
+            bias = ops.pack_vector(P[f"b{k}.c2b"], 2 * d.D2p, d.D2, d.D2p)
+            c2 = ops.conv_gemm(x, w, rows(f"b{k}.c2", 2 * d.D2p), B=B, T=T, KS=3, dil=dil[2], bias=bias, alg_dims=(d.D2, 2 * d.D2))
+            x = ops.glu_forward(c2, rows(f"x{k + 1}", d.D2p), B, T)
+            bufs[f"b{k}.c2"], bufs[f"x{k + 1}"] = c2, x
+
+        # ---- two 1x1 projections with GELU (models.py:194-195)
+        w = packw("f1w", P["f1w"], d.F1p, d.D2p)
+        u1, g1 = rows("u1", d.F1p), rows("g1", d.F1p)
+        ops.conv_gemm(x, w, g1, B=B, T=T, KS=1, dil=0, bias=ops.pack_vector(P["f1b"], d.F1p), y_pre=u1 if need_grad else None,
+                      gelu=True, alg_dims=(d.D2, d.F1))
+        w = packw("f2w", P["f2w"], d.Fp, d.F1p)
+        u2, Zt = rows("u2", d.Fp), self._rows("Z", B, T, d.Fp, dev, space)
+        ops.conv_gemm(g1, w, Zt, B=B, T=T, KS=1, dil=0, bias=ops.pack_vector(P["f2b"], d.Fp), y_pre=u2 if need_grad else None,
+                      gelu=True, alg_dims=(d.F1, d.F))
+        bufs.update(u1=u1, g1=g1, u2=u2, Z=Zt)
+        if not need_grad:
+            ctx.bufs = {"Z": Zt}
+            ctx.packed = {}
+        return ctx
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, P: Dict[str, torch.Tensor], ctx: EncoderCtx, dZt: torch.Tensor) -> Dict[str, torch.Tensor]:
+        if ctx.gen != self._gen and self.reuse_workspace:
+            raise L.SdaError("the activation workspace of this forward was overwritten by a later forward of the same "
+                             "encoder; call backward before the next training-mode forward, or set "
+                             "engine.reuse_workspace = False")
+        d, dt = self.d, self.dtype
+        B, T, bufs = ctx.B, ctx.T, ctx.bufs
+        dev = dZt.device
+        grads: Dict[str, torch.Tensor] = {}
+        scratch = ops.reduce_scratch(max(d.Fp, 2 * d.D2p, d.F1p), dev)
+
+        def tmp(name, Cp):
+            return self._rows("bw." + name, B, T, Cp, dev, "train")
+
+        def wgrad(dy, x, KS, dil, Cout, Cin, **glu):
+            Cout_p, Cin_p = dy.shape[1], x.shape[1]
+            tile_m = 160 if Cout_p % 160 == 0 else (128 if Cout_p % 128 == 0 else 64)
+            perm, seg, nseg = self._uniform_segments(B, (Cout_p // tile_m) * (Cin_p // 64), dev)
+            slabs = ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=perm, seg_start=seg, nseg=nseg)
+            g = ops.reduce_slabs(slabs)
+            return ops.unpack_conv_wgrad(g, 1, Cout, Cin, KS, Cout_p, Cin_p, **glu)[0]
+
+        def dgrad(dy, key, w_fp32, Cout_p, Cin_p, out, KS, dil, res=None, widx=None, **glu):
+            wt = ops.pack_conv_weight(w_fp32, Cout_p, Cin_p, dt, mode=1, **glu)
+            return ops.conv_gemm(dy, wt, out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx,
+                                 alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]))
+
+        # ---- final projections
+        du2 = ops.gelu_backward(bufs["u2"], dZt, tmp("du2", d.Fp), B, T)
+        grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
+        grads["f2b"] = ops.unpack_vector(ops.colsum(du2, B, T, scratch), d.F)
+        dg1 = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
+        du1 = ops.gelu_backward(bufs["u1"], dg1, tmp("du1", d.F1p), B, T)
+        grads["f1w"] = wgrad(du1, bufs["x5"], 1, 0, d.F1, d.D2)
+        grads["f1b"] = ops.unpack_vector(ops.colsum(du1, B, T, scratch), d.F1)
+        dx = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
+
+        # ---- ConvBlocks, last to first
+        flip = 0
+        for k in range(4, -1, -1):
+            cin, cin_p = (d.D1, d.D1p) if k == 0 else (d.D2, d.D2p)
+            dil = block_dilations(k)
+            glu = dict(glu_half=d.D2, glu_half_p=d.D2p)
+            dc2 = ops.glu_backward(bufs[f"b{k}.c2"], dx, tmp("dc2", 2 * d.D2p), B, T)
+            grads[f"b{k}.c2w"] = wgrad(dc2, bufs[f"b{k}.a1"], 3, dil[2], 2 * d.D2, d.D2, **glu)
+            grads[f"b{k}.c2b"] = ops.unpack_vector(ops.colsum(dc2, B, T, scratch), 2 * d.D2, **glu)
+            da1 = dgrad(dc2, None, P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2], **glu)
+            x_in = bufs[f"x{k}"]
+            for j in (1, 0):
+                bnp = f"b{k}.bn{j}"
+                mean, rstd = ctx.bn[bnp]
+                dh = tmp("dh", d.D2p)
+                world = self.world
+                dgam, dbet = ops.bn_gelu_backward(da1, bufs[f"b{k}.h{j}"], mean, rstd, P[bnp + "w"], P[bnp + "b"], dh, B, T,
+                                                  scratch, count=float(B) * T * world,
+                                                  allreduce=self._allreduce if world > 1 else None)
+                # under DP the sums are already global on every rank; the gradient all-reduce (SUM) follows
+                grads[bnp + "w"], grads[bnp + "b"] = dgam[: d.D2] / world, dbet[: d.D2] / world
+                src = bufs[f"b{k}.a0"] if j == 1 else x_in
+                ci, ci_p = (d.D2, d.D2p) if j == 1 else (cin, cin_p)
+                grads[f"b{k}.c{j}w"] = wgrad(dh, src, 3, dil[j], d.D2, ci)
+                grads[f"b{k}.c{j}b"] = ops.unpack_vector(ops.colsum(dh, B, T, scratch), d.D2)
+                res = dh if (j == 1 or k > 0) else None
+                out = tmp("da", d.D2p) if j == 1 else tmp("dxB" if flip == 0 else "dxA", ci_p)
+                da1 = dgrad(dh, None, P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res)
+            dx = da1
+            flip ^= 1
+
+        # ---- SubjectBlock
+        dhs = dx                                            # (rows, D1p)
+        slabs = ops.wgrad_gemm(dhs, bufs["h_c"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg, nseg=d.S)
+        grads["subj_w"] = ops.unpack_conv_wgrad(slabs, d.S, d.D1, d.D1, 1, d.D1p, d.D1p)
+        dh_c = dgrad(dhs, None, P["subj_w"], d.D1p, d.D1p, tmp("dh_c", d.D1p), 1, 0, widx=ctx.widx)
+        grads["sb_w"] = wgrad(dh_c, bufs["h_sa"], 1, 0, d.D1, d.D1)
+        grads["sb_b"] = ops.unpack_vector(ops.colsum(dh_c, B, T, scratch), d.D1)
+        dh_sa = dgrad(dh_c, None, P["sb_w"], d.D1p, d.D1p, tmp("dh_sa", d.D1p), 1, 0)
+        Cout_p, Cin_p = d.D1p, d.Cp
+        tile_m = 160 if Cout_p % 160 == 0 else (128 if Cout_p % 128 == 0 else 64)
+        perm, seg, nseg = self._uniform_segments(B, (Cout_p // tile_m) * (Cin_p // 64), dev)
+        dWd = ops.reduce_slabs(ops.wgrad_gemm(dh_sa, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=perm, seg_start=seg, nseg=nseg))
+        grads["z"] = ops.sa_weights_backward(dWd, ctx.W_sa, ctx.mask, P["cosT"], P["sinT"], P["z"].shape[1])
+        return grads
+
+
+# ----------------------------------------------------------------------------------------------- loss
+@dataclass
+class ClipCtx:
+    Bm: int
+    Bn: int
+    col0: int
+    G: torch.Tensor
+    rscale: torch.Tensor
+    Yt: torch.Tensor
+    Zt: torch.Tensor
+    row_elems: int
+    dtemp: torch.Tensor
+
+
+def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: int, Bn: int, T: int, col0: int = 0,
+                 reduction: str = "mean", B_global: Optional[int] = None, dist_group=None, want_grad: bool = True):
+    """CLIP loss (loss.py:58-79) on RL embeddings: Yt holds the Bm (global) speech rows, Zt the Bn local
+    brain rows.  Returns (loss_local_share, logits, ranks_count, ctx).  With `dist_group`, row statistics
+    and the diagonal are merged across ranks so that the negatives span the global batch."""
+    import torch.distributed as dist
+    Fp = Zt.shape[1]
+    row_elems = L.rows_tp(T) * Fp
+    ysq = ops.rows_sumsq(Yt, Bm, row_elems, row_elems)
+    zsq = ops.rows_sumsq(Zt, Bn, row_elems, row_elems)
+    S = ops.matmul_nt_splitk(Yt, Zt, Bm, Bn, row_elems, row_elems)
+    logits, row_max, row_sum, col_lse, diag = ops.clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0)
+    if dist_group is not None and dist.get_world_size(dist_group) > 1:
+        gmax = row_max.clone()
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=dist_group)
+        row_sum = row_sum * torch.exp(row_max - gmax)
+        dist.all_reduce(row_sum, op=dist.ReduceOp.SUM, group=dist_group)
+        dist.all_reduce(diag, op=dist.ReduceOp.SUM, group=dist_group)     # zero where not owned
+        row_max = gmax
+    row_lse = row_max + torch.log(row_sum)
+    Bg = B_global if B_global is not None else Bm
+    inv_norm = 1.0 / (2.0 * Bg) if reduction == "mean" else 0.5
+    G, rscale, scalars = ops.clip_grad(logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, Yt.dtype)
+    cnt = ops.clip_ranks(logits, diag, col0)
+    ctx = ClipCtx(Bm=Bm, Bn=Bn, col0=col0, G=G, rscale=rscale, Yt=Yt, Zt=Zt, row_elems=row_elems, dtemp=scalars[1:2])
+    return scalars[0:1], logits, cnt, ctx
+
+
+def clip_backward(ctx: ClipCtx, dZt: torch.Tensor) -> torch.Tensor:
+    """dZ = G^T Y - diag(r) Z  (gradient of the loss share w.r.t. the local brain embeddings)."""
+    return ops.matmul_tn_typed(ctx.G, ctx.Yt, dZt, ctx.Zt, ctx.rscale, M_rows=ctx.Bm, N_valid=ctx.Bn,
+                               K_cols=ctx.row_elems, pitch=ctx.row_elems)

@@ -1,0 +1,115 @@
+"""ctypes binding of libsdamd.so (C ABI declared in include/sd_amd.h).
+
+There is NO fallback: if the shared library is missing or an entry point fails, this raises.  The
+library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdamd.so")
+
+F32, BF16 = 0, 1
+ROW_PAD = 16
+CH_ALIGN = 64
+EPI_GELU = 1
+
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("res", vp), ("y", vp), ("y_pre", vp), ("widx", vp),
+                ("stats", vp), ("partial", vp),
+                ("B", i32), ("T", i32), ("Cin_p", i32), ("Cout_p", i32), ("KS", i32), ("dil", i32),
+                ("x_pitch", i64), ("w_pitch", i64), ("x_row0", i64), ("x_sample_rows", i64),
+                ("x_rows_limit", i64), ("w_rows_limit", i32), ("ksplit", i32), ("flags", i32), ("dtype", i32)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("dy", vp), ("x", vp), ("g", vp), ("out_e", vp), ("sub", vp), ("rscale", vp), ("perm", vp),
+                ("seg_start", vp),
+                ("nseg", i32), ("B", i32), ("T", i32), ("Cout_p", i32), ("Cin_p", i32), ("KS", i32), ("dil", i32),
+                ("dy_pitch", i64), ("x_pitch", i64), ("out_pitch", i64), ("row0", i64), ("sample_rows", i64),
+                ("rows_limit", i64), ("co_valid", i32), ("dtype", i32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/sd_amd.h
+SIGNATURES = {
+    "sda_abi_version": (i32, []),
+    "sda_last_error": (C.c_char_p, []),
+    "sda_rows_alloc": (i64, [i32, i32]),
+    "sda_pad_channels": (i32, [i32]),
+    "sda_device_count": (i32, []),
+    "sda_pack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sda_unpack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sda_rows_sumsq": (i32, [vp, vp, vp, i32, i64, i64, i32, vp]),
+    "sda_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "sda_pack_vector": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "sda_unpack_conv_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "sda_unpack_vector": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "sda_conv_gemm": (i32, [C.POINTER(ConvArgs), vp]),
+    "sda_conv_n_t_tiles": (i32, [i32]),
+    "sda_bn_finalize": (i32, [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "sda_bn_gelu_forward": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_bn_gelu_backward_reduce": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_bn_gelu_backward_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, f64, vp, i32, i32, i32, i32, vp]),
+    "sda_reduce_scratch_floats": (i32, [i32]),
+    "sda_glu_forward": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "sda_glu_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_gelu_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_colsum": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_wgrad_gemm": (i32, [C.POINTER(WgradArgs), vp]),
+    "sda_reduce_slabs": (i32, [vp, vp, i32, i64, vp]),
+    "sda_sa_weights_forward": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "sda_sa_weights_backward": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_clip_logits_stats": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "sda_clip_grad": (i32, [vp, vp, vp, vp, vp, vp, f32, i32, vp, i64, vp, vp, vp, i32, i32, i32, vp]),
+    "sda_clip_ranks": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+}
+
+_lib = None
+
+
+class SdaError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsdamd.so and bind every declared symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SdaError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C speech_decoding_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sda_abi_version() != 1:
+        raise SdaError("libsdamd.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().sda_last_error()
+        raise SdaError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def pad_channels(c: int) -> int:
+    return (c + CH_ALIGN - 1) // CH_ALIGN * CH_ALIGN
+
+
+def rows_tp(T: int) -> int:
+    return T + ROW_PAD
+
+
+def rows_alloc(B: int, T: int) -> int:
+    return B * rows_tp(T) + ROW_PAD + 128 + 2 * ROW_PAD

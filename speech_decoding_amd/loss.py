@@ -1,0 +1,155 @@
+"""MI355X-native `CLIPLoss` with the reference's signature (speech_decoding/utils/loss.py:28-84).
+
+forward(x, y, fast=True, return_logits=False): x = speech embeddings Y (B, F, T), y = brain embeddings
+Z (B, F, T); loss = (CE(logits) + CE(logitsᵀ)) / 2 with logits = x̂ ŷᵀ · exp(temp).  The norms, the
+similarity GEMM, the softmax statistics, the gradient coefficient matrix and the embedding gradient
+all run in libsdamd.so.  Under torch.distributed (one process per GPU) the speech rows are all-gathered
+so the negatives span the GLOBAL batch; each rank owns the columns of its local brain embeddings.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from . import ops
+from . import engine as E
+
+import weakref
+
+_rank_cache = []          # [(weakref(Y), weakref(Z), ranks)] from the last CLIPLoss forward
+
+
+def _cache_ranks(Y, Z, cnt):
+    _rank_cache.clear()
+    _rank_cache.append((weakref.ref(Y), weakref.ref(Z), cnt))
+
+
+def _cached_ranks(Y, Z):
+    for wy, wz, cnt in _rank_cache:
+        if wy() is Y and wz() is Z:
+            return cnt
+    return None
+
+
+def _rows_base(t: torch.Tensor, B: int, Cc: int, T: int, dtype):
+    """If `t` is a (B, C, T) view laid out exactly like ops.rows_view(...) of an RL buffer, return that
+    buffer as a (rows_alloc, Cp) tensor sharing its storage (zero copy); else None."""
+    if t.dtype != dtype or not t.is_cuda or t.dim() != 3:
+        return None
+    Cp, rows = L.pad_channels(Cc), L.rows_alloc(B, T)
+    if tuple(t.stride()) != (L.rows_tp(T) * Cp, 1, Cp) or t.storage_offset() != L.ROW_PAD * Cp:
+        return None
+    if t.untyped_storage().nbytes() < rows * Cp * t.element_size():
+        return None
+    return t.detach().as_strided((rows, Cp), (Cp, 1), 0)
+
+
+def as_rows(t: torch.Tensor, B: int, Cc: int, T: int, dtype, name: str) -> torch.Tensor:
+    """Return the RL buffer behind `t` (zero copy when `t` is a rows_view made by this package), else
+    pack a plain (B, C, T) tensor into a fresh RL buffer."""
+    if tuple(t.shape) != (B, Cc, T):
+        raise ValueError(f"{name}: expected shape {(B, Cc, T)}, got {tuple(t.shape)}")
+    base = _rows_base(t, B, Cc, T, dtype)
+    if base is not None:
+        return base
+    if not t.is_cuda:
+        raise L.SdaError(f"{name} must live on the MI355X device (there is no CPU path)")
+    buf = ops.new_rows(B, T, L.pad_channels(Cc), dtype, t.device)
+    ops.pack_rows(t.detach().float().contiguous(), buf)
+    return buf
+
+
+def _dist_group():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.group.WORLD
+    return None
+
+
+class _ClipFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module: "CLIPLoss", Y, Z, temp):
+        import torch.distributed as dist
+        B, F, T = Z.shape
+        dtype = Z.dtype if Z.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        Zt = as_rows(Z, B, F, T, dtype, "y (brain embeddings)")
+        Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)")
+        group = _dist_group() if module.global_negatives else None
+        if group is not None:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            Tp, Fp = L.rows_tp(T), Zt.shape[1]
+            Yt = ops.new_rows(B * world, T, Fp, dtype, Zt.device)
+            # samples are contiguous blocks of Tp rows, so the gather lands directly in RL order
+            dist.all_gather_into_tensor(Yt[: B * world * Tp], Yt_local[: B * Tp].contiguous(), group=group)
+            Bm, col0, Bg = B * world, rank * B, B * world
+        else:
+            Yt, Bm, col0, Bg = Yt_local, B, 0, B
+        loss, logits, cnt, cctx = E.clip_forward(Yt, Zt, temp.detach(), Bm=Bm, Bn=B, T=T, col0=col0,
+                                                 reduction=module.reduction, B_global=Bg, dist_group=group)
+        if group is not None:
+            dist.all_reduce(cnt, group=group)
+            dist.all_reduce(loss, group=group)          # report the global loss; backward uses the local share
+        ctx.cctx, ctx.shape, ctx.dtype, ctx.group = cctx, (B, F, T), dtype, group
+        ctx.z_requires_grad = Z.requires_grad
+        _cache_ranks(Y, Z, cnt[col0: col0 + B])
+        ctx.mark_non_differentiable(logits)
+        return loss.reshape(()), logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits):
+        c = ctx.cctx
+        B, F, T = ctx.shape
+        dZ = None
+        scale = dloss.to(torch.float32)
+        if ctx.z_requires_grad:
+            G = (c.G.float() * scale).to(c.G.dtype)          # fold the incoming scalar gradient (B x B, tiny)
+            rscale = c.rscale * scale
+            c2 = E.ClipCtx(c.Bm, c.Bn, c.col0, G, rscale, c.Yt, c.Zt, c.row_elems, c.dtemp)
+            dZt = ops.new_rows(B, T, c.Zt.shape[1], ctx.dtype, c.Zt.device)
+            E.clip_backward(c2, dZt)
+            dZ = ops.rows_view(dZt, B, F, T)
+        dtemp = (c.dtemp * scale).reshape(1)
+        return None, None, dZ, dtemp
+
+
+class CLIPLoss(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        L.load()
+        self.reduction = str(args.reduction)
+        if self.reduction not in ("mean", "sum"):
+            raise ValueError("reduction must be 'mean' or 'sum'")
+        self.temp = nn.Parameter(torch.tensor([float(args.init_temperature)]))
+        self.global_negatives = True
+        self.last_logits: Optional[torch.Tensor] = None
+
+    def forward(self, x, y, fast=True, return_logits=False):
+        batch_size = x.size(0)
+        assert batch_size > 1, "Batch size must be greater than 1."               # loss.py:40
+        if not fast:
+            raise NotImplementedError("fast=False (loss.py:46-50, unscaled cosine logits) is never used by the "
+                                      "training path and is not provided by the HIP build")
+        loss, logits = _ClipFn.apply(self, x, y, self.temp)
+        self.last_logits = logits
+        if return_logits:
+            return logits, loss
+        return loss
+
+
+@torch.no_grad()
+def retrieval_ranks(Y: torch.Tensor, Z: torch.Tensor) -> torch.Tensor:
+    """Rank of each speech row's own brain column (0 = top-1).  Reuses the ranks computed by the last
+    CLIPLoss forward on the same tensors; otherwise runs the similarity GEMM + rank kernel."""
+    hit = _cached_ranks(Y, Z)
+    if hit is not None:
+        return hit
+    B, F, T = Z.shape
+    dtype = Z.dtype if Z.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    Zt = as_rows(Z, B, F, T, dtype, "Z")
+    Yt = as_rows(Y, B, F, T, dtype, "Y")
+    temp = torch.zeros(1, dtype=torch.float32, device=Zt.device)
+    _, _, cnt, _ = E.clip_forward(Yt, Zt, temp, Bm=B, Bn=B, T=T)
+    return cnt

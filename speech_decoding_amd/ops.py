@@ -1,0 +1,325 @@
+"""Thin torch-tensor wrappers over the C ABI (include/sd_amd.h).  torch is used only for device
+memory and the current HIP stream; every computation happens inside libsdamd.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise L.SdaError(f"unsupported compute dtype {dtype}; use torch.float32 or torch.bfloat16")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.SdaError("libsdamd kernels need device tensors (no CPU fallback)")
+
+
+def new_rows(B: int, T: int, Cp: int, dtype, device) -> torch.Tensor:
+    """Zero-initialised RL buffer: (rows_alloc, Cp)."""
+    return torch.zeros((L.rows_alloc(B, T), Cp), dtype=dtype, device=device)
+
+
+def rows_view(buf: torch.Tensor, B: int, C: int, T: int) -> torch.Tensor:
+    """(B, C, T) strided view of an RL buffer (zero copy): element (b, c, t) = buf[b*Tp + PAD + t, c]."""
+    Tp, Cp = L.rows_tp(T), buf.shape[1]
+    return buf.as_strided((B, C, T), (Tp * Cp, 1, Cp), L.ROW_PAD * Cp)
+
+
+def pack_rows(src: torch.Tensor, dst: torch.Tensor):
+    _need_cuda(src, dst)
+    B, Cc, T = src.shape
+    src = src.contiguous().float()
+    L.check(L.load().sda_pack_rows(_p(src), _p(dst), B, Cc, T, dst.shape[1], dt_code(dst.dtype), _st()), "pack_rows")
+
+
+def unpack_rows(src: torch.Tensor, B: int, Cc: int, T: int) -> torch.Tensor:
+    _need_cuda(src)
+    out = torch.empty((B, Cc, T), dtype=torch.float32, device=src.device)
+    L.check(L.load().sda_unpack_rows(_p(src), _p(out), B, Cc, T, src.shape[1], dt_code(src.dtype), _st()), "unpack_rows")
+    return out
+
+
+def rows_sumsq(x: torch.Tensor, B: int, row_elems: int, pitch: int) -> torch.Tensor:
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(B * 64, dtype=torch.float32, device=x.device)
+    L.check(L.load().sda_rows_sumsq(_p(x), _p(out), _p(scratch), B, row_elems, pitch, dt_code(x.dtype), _st()), "rows_sumsq")
+    return out
+
+
+def pack_conv_weight(w: torch.Tensor, Cout_p: int, Cin_p: int, dtype, mode: int = 0, glu_half: int = 0,
+                     glu_half_p: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """w: (nW, Cout, Cin, KS) or (Cout, Cin, KS) fp32 -> packed operand (nW, KS, rows, cols)."""
+    if w.dim() == 3:
+        w = w.unsqueeze(0)
+    nW, Cout, Cin, KS = w.shape
+    w = w.contiguous()
+    rows, cols = (Cout_p, Cin_p) if mode == 0 else (Cin_p, Cout_p)
+    if out is None:
+        out = torch.empty((nW, KS, rows, cols), dtype=dtype, device=w.device)
+    L.check(L.load().sda_pack_conv_weight(_p(w), _p(out), nW, Cout, Cin, KS, Cout_p, Cin_p, mode, glu_half, glu_half_p,
+                                          dt_code(dtype), _st()), "pack_conv_weight")
+    return out
+
+
+def pack_vector(v: torch.Tensor, Cp: int, glu_half: int = 0, glu_half_p: int = 0) -> torch.Tensor:
+    out = torch.empty(Cp, dtype=torch.float32, device=v.device)
+    L.check(L.load().sda_pack_vector(_p(v.contiguous()), _p(out), v.numel(), Cp, glu_half, glu_half_p, _st()), "pack_vector")
+    return out
+
+
+def unpack_conv_wgrad(g: torch.Tensor, nW, Cout, Cin, KS, Cout_p, Cin_p, glu_half=0, glu_half_p=0) -> torch.Tensor:
+    out = torch.empty((nW, Cout, Cin, KS), dtype=torch.float32, device=g.device)
+    L.check(L.load().sda_unpack_conv_wgrad(_p(g), _p(out), nW, Cout, Cin, KS, Cout_p, Cin_p, glu_half, glu_half_p, _st()),
+            "unpack_conv_wgrad")
+    return out
+
+
+def unpack_vector(g: torch.Tensor, Cc: int, glu_half=0, glu_half_p=0) -> torch.Tensor:
+    out = torch.empty(Cc, dtype=torch.float32, device=g.device)
+    L.check(L.load().sda_unpack_vector(_p(g), _p(out), Cc, g.numel(), glu_half, glu_half_p, _st()), "unpack_vector")
+    return out
+
+
+class KernelTimer:
+    """Optional HIP-event timing of individual launches on the current stream (bench.py's roofline leg).
+    Off by default: `ops.TIMER = KernelTimer()` turns it on, `ops.TIMER = None` off."""
+
+    def __init__(self):
+        self.records = []           # (key, algorithmic_flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, flops, e0, e1 in self.records:
+            n, f, ms = out.get(key, (0, 0.0, 0.0))
+            out[key] = (n + 1, f + flops, ms + e0.elapsed_time(e1))
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def conv_tile_co(Cout_p: int) -> int:
+    return 160 if Cout_p % 160 == 0 else (128 if Cout_p % 128 == 0 else 64)
+
+
+def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=None, stats=None, gelu=False,
+              alg_dims=None):
+    """RL conv: x (rows, Cin_p), w (nW, KS, Cout_p, Cin_p) packed, y (rows, Cout_p).
+    alg_dims = (Cin, Cout) unpadded, only used to count algorithmic FLOPs when the timer is on."""
+    _need_cuda(x, w, y)
+    a = L.ConvArgs()
+    a.x, a.w, a.bias, a.res, a.y, a.y_pre = _p(x), _p(w), _p(bias), _p(res), _p(y), _p(y_pre)
+    a.widx, a.stats, a.partial = _p(widx), _p(stats), None
+    a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = B, T, x.shape[1], y.shape[1], KS, dil
+    if w.shape[-1] != x.shape[1] or w.shape[-2] != y.shape[1] or w.shape[-3] != KS:
+        raise L.SdaError(f"conv_gemm: weight {tuple(w.shape)} does not match x {tuple(x.shape)} / y {tuple(y.shape)}")
+    a.x_pitch, a.w_pitch = x.shape[1], w.shape[-1]
+    a.x_row0, a.x_sample_rows, a.x_rows_limit = L.ROW_PAD, L.rows_tp(T), x.shape[0]
+    if x.shape[0] < L.rows_alloc(B, T) or y.shape[0] < L.rows_alloc(B, T):
+        raise L.SdaError("conv_gemm: RL buffers too small for (B, T)")
+    a.w_rows_limit, a.ksplit = y.shape[1], 1
+    a.flags, a.dtype = (L.EPI_GELU if gelu else 0), dt_code(x.dtype)
+    if TIMER is not None:
+        cin, cout = alg_dims if alg_dims is not None else (x.shape[1], y.shape[1])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.load().sda_conv_gemm(C.byref(a), _st()), "conv_gemm")
+        e1.record()
+        TIMER.records.append((("conv_gemm", str(x.dtype).replace("torch.", ""), conv_tile_co(y.shape[1]), KS),
+                              2.0 * B * T * KS * cin * cout, e0, e1))
+        return y
+    L.check(L.load().sda_conv_gemm(C.byref(a), _st()), "conv_gemm")
+    return y
+
+
+def n_t_tiles(T: int) -> int:
+    return (T + 127) // 128
+
+
+def matmul_nt_splitk(xm: torch.Tensor, wm: torch.Tensor, M: int, N: int, K: int, pitch: int) -> torch.Tensor:
+    """S[i][j] = sum_k xm[i][k] * wm[j][k] (both K-contiguous rows with `pitch`), fp32 (M, pad64(N)) result.
+    Runs conv_gemm in split-K mode + ordered slab reduction (loss.py:68)."""
+    Np = L.pad_channels(N)
+    slab = 64 if xm.dtype == torch.bfloat16 else 32
+    nslab = K // slab
+    tile_co = 160 if Np % 160 == 0 else (128 if Np % 128 == 0 else 64)
+    tiles = ((M + 127) // 128) * (Np // tile_co)
+    ksplit = max(1, min(nslab, (512 + tiles - 1) // tiles))
+    partial = torch.empty((ksplit, M, Np), dtype=torch.float32, device=xm.device)
+    a = L.ConvArgs()
+    a.x, a.w, a.bias, a.res, a.y, a.y_pre, a.widx, a.stats = _p(xm), _p(wm), None, None, None, None, None, None
+    a.partial = _p(partial)
+    a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = 1, M, K, Np, 1, 0
+    a.x_pitch, a.w_pitch, a.x_row0, a.x_sample_rows, a.x_rows_limit = pitch, pitch, 0, 0, M
+    a.w_rows_limit, a.ksplit, a.flags, a.dtype = N, ksplit, 0, dt_code(xm.dtype)
+    L.check(L.load().sda_conv_gemm(C.byref(a), _st()), "conv_gemm(split-K)")
+    if ksplit == 1:
+        return partial[0]
+    out = torch.empty((M, Np), dtype=torch.float32, device=xm.device)
+    L.check(L.load().sda_reduce_slabs(_p(partial), _p(out), ksplit, M * Np, _st()), "reduce_slabs")
+    return out
+
+
+def bn_finalize(partial, ntiles, count, gamma, beta, running_mean, running_var, Cp, training, eps=1e-5, momentum=0.1):
+    dev = gamma.device
+    mean, rstd, scale, shift = (torch.empty(Cp, dtype=torch.float32, device=dev) for _ in range(4))
+    L.check(L.load().sda_bn_finalize(_p(partial), ntiles, float(count), _p(gamma), _p(beta), eps, momentum,
+                                     _p(running_mean), _p(running_var), _p(mean), _p(rstd), _p(scale), _p(shift),
+                                     gamma.numel(), Cp, int(training), _st()), "bn_finalize")
+    return mean, rstd, scale, shift
+
+
+def bn_gelu_forward(x, y, scale, shift, B, T):
+    L.check(L.load().sda_bn_gelu_forward(_p(x), _p(y), _p(scale), _p(shift), B, T, x.shape[1], dt_code(x.dtype), _st()),
+            "bn_gelu_forward")
+    return y
+
+
+def reduce_scratch(Cp, device):
+    return torch.empty(L.load().sda_reduce_scratch_floats(Cp), dtype=torch.float32, device=device)
+
+
+def bn_gelu_backward(dy, x, mean, rstd, gamma, beta, dx, B, T, scratch, count=None, allreduce=None):
+    """Returns (dgamma, dbeta) summed over `count` rows (global sums when `allreduce` is given) and fills dx."""
+    Cp = x.shape[1]
+    sums = torch.empty((2, Cp), dtype=torch.float32, device=x.device)
+    dgamma, dbeta = sums[0], sums[1]
+    lib = L.load()
+    L.check(lib.sda_bn_gelu_backward_reduce(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), gamma.numel(), _p(scratch),
+                                            _p(dgamma), _p(dbeta), B, T, Cp, dt_code(x.dtype), _st()), "bn_gelu_backward_reduce")
+    if allreduce is not None:
+        allreduce(sums)
+    L.check(lib.sda_bn_gelu_backward_apply(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), gamma.numel(), _p(dgamma),
+                                           _p(dbeta), float(count if count is not None else B * T), _p(dx), B, T, Cp,
+                                           dt_code(x.dtype), _st()), "bn_gelu_backward_apply")
+    return dgamma, dbeta
+
+
+def glu_forward(x, y, B, T):
+    L.check(L.load().sda_glu_forward(_p(x), _p(y), B, T, y.shape[1], dt_code(x.dtype), _st()), "glu_forward")
+    return y
+
+
+def glu_backward(x, dy, dx, B, T):
+    L.check(L.load().sda_glu_backward(_p(x), _p(dy), _p(dx), B, T, dy.shape[1], dt_code(x.dtype), _st()), "glu_backward")
+    return dx
+
+
+def gelu_backward(u, dz, du, B, T):
+    L.check(L.load().sda_gelu_backward(_p(u), _p(dz), _p(du), B, T, u.shape[1], dt_code(u.dtype), _st()), "gelu_backward")
+    return du
+
+
+def colsum(x, B, T, scratch):
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    L.check(L.load().sda_colsum(_p(x), _p(out), _p(scratch), B, T, x.shape[1], dt_code(x.dtype), _st()), "colsum")
+    return out
+
+
+def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1):
+    """fp32 slabs (nseg, KS, Cout_p, Cin_p) of dy^T x over the RL rows of the samples in each segment."""
+    a = L.WgradArgs()
+    g = torch.empty((nseg, KS, dy.shape[1], x.shape[1]), dtype=torch.float32, device=x.device)
+    a.dy, a.x, a.g, a.out_e, a.sub, a.rscale = _p(dy), _p(x), _p(g), None, None, None
+    a.perm, a.seg_start = _p(perm), _p(seg_start)
+    a.nseg, a.B, a.T, a.Cout_p, a.Cin_p, a.KS, a.dil = nseg, B, T, dy.shape[1], x.shape[1], KS, dil
+    a.dy_pitch, a.x_pitch, a.out_pitch = dy.shape[1], x.shape[1], 0
+    a.row0, a.sample_rows, a.rows_limit = L.ROW_PAD, L.rows_tp(T), x.shape[0]
+    a.co_valid, a.dtype = 0, dt_code(x.dtype)
+    if nseg > 1 and seg_start is None:
+        raise L.SdaError("wgrad_gemm: nseg > 1 needs seg_start")
+    L.check(L.load().sda_wgrad_gemm(C.byref(a), _st()), "wgrad_gemm")
+    return g
+
+
+def reduce_slabs(slabs: torch.Tensor) -> torch.Tensor:
+    n = slabs[0].numel()
+    if slabs.shape[0] == 1:
+        return slabs[0]
+    out = torch.empty_like(slabs[0])
+    L.check(L.load().sda_reduce_slabs(_p(slabs), _p(out), slabs.shape[0], n, _st()), "reduce_slabs")
+    return out
+
+
+def matmul_tn_typed(G, Ym, out, sub, rscale, *, M_rows, N_valid, K_cols, pitch):
+    """out[j][k] = sum_i G[i][j] * Ym[i][k] - rscale[j] * sub[j][k]   (typed rows with `pitch`; loss backward)."""
+    a = L.WgradArgs()
+    a.dy, a.x, a.g, a.out_e, a.sub, a.rscale = _p(G), _p(Ym), None, _p(out), _p(sub), _p(rscale)
+    a.perm, a.seg_start = None, None
+    a.nseg, a.B, a.T, a.Cout_p, a.Cin_p, a.KS, a.dil = 1, 1, M_rows, G.shape[1], K_cols, 1, 0
+    a.dy_pitch, a.x_pitch, a.out_pitch = G.shape[1], pitch, pitch
+    a.row0, a.sample_rows, a.rows_limit = 0, 0, M_rows
+    a.co_valid, a.dtype = N_valid, dt_code(Ym.dtype)
+    L.check(L.load().sda_wgrad_gemm(C.byref(a), _st()), "wgrad_gemm(typed)")
+    return out
+
+
+def sa_weights_forward(z, cos_t, sin_t, mask, D1p, Cp, dtype):
+    D1, K2 = z.shape
+    Cc = cos_t.shape[1]
+    zr = torch.view_as_real(z).contiguous()
+    W = torch.empty((D1, Cc), dtype=torch.float32, device=z.device)
+    Wp = torch.empty((1, 1, D1p, Cp), dtype=dtype, device=z.device)
+    L.check(L.load().sda_sa_weights_forward(_p(zr), _p(cos_t), _p(sin_t), _p(mask), _p(W), _p(Wp), D1, K2, Cc, D1p, Cp,
+                                            dt_code(dtype), _st()), "sa_weights_forward")
+    return W, Wp
+
+
+def sa_weights_backward(dWd, W, mask, cosT, sinT, K2):
+    D1, Cc = W.shape
+    dz = torch.empty((D1, K2, 2), dtype=torch.float32, device=W.device)
+    L.check(L.load().sda_sa_weights_backward(_p(dWd), _p(W), _p(mask), _p(cosT), _p(sinT), _p(dz), D1, K2, Cc, dWd.shape[-1],
+                                             _st()), "sa_weights_backward")
+    return torch.view_as_complex(dz)
+
+
+def clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0):
+    dev = S.device
+    logits = torch.empty((Bm, Bn), dtype=torch.float32, device=dev)
+    row_max = torch.empty(Bm, dtype=torch.float32, device=dev)
+    row_sum = torch.empty(Bm, dtype=torch.float32, device=dev)
+    col_lse = torch.empty(Bn, dtype=torch.float32, device=dev)
+    diag = torch.zeros(Bm, dtype=torch.float32, device=dev)
+    L.check(L.load().sda_clip_logits_stats(_p(S), S.shape[1], _p(ysq), _p(zsq), _p(temp), _p(logits), _p(row_max), _p(row_sum),
+                                           _p(col_lse), _p(diag), Bm, Bn, col0, _st()), "clip_logits_stats")
+    return logits, row_max, row_sum, col_lse, diag
+
+
+def clip_grad(logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, dtype):
+    Bm, Bn = logits.shape
+    dev = logits.device
+    G = torch.zeros((Bm, L.pad_channels(Bn)), dtype=dtype, device=dev)
+    rscale = torch.empty(Bn, dtype=torch.float32, device=dev)
+    colpart = torch.empty(2 * Bn, dtype=torch.float32, device=dev)
+    scalars = torch.empty(2, dtype=torch.float32, device=dev)
+    L.check(L.load().sda_clip_grad(_p(logits), _p(row_lse), _p(col_lse), _p(ysq), _p(zsq), _p(temp), float(inv_norm), col0,
+                                   _p(G), G.shape[1], _p(rscale), _p(colpart), _p(scalars), Bm, Bn, dt_code(dtype), _st()),
+            "clip_grad")
+    return G, rscale, scalars
+
+
+def clip_ranks(logits, diag, col0):
+    Bm, Bn = logits.shape
+    cnt = torch.empty(Bm, dtype=torch.int32, device=logits.device)
+    L.check(L.load().sda_clip_ranks(_p(logits), _p(diag), _p(cnt), Bm, Bn, col0, _st()), "clip_ranks")
+    return cnt

@@ -1,0 +1,318 @@
+"""Kernel-level parity on a real MI355X: every C-ABI stage against the CPU oracle / plain torch fp32
+on the same seeded inputs.  fp32 mode runs on the exact-f32 MFMA (tolerance 1e-5..1e-4 relative);
+bf16 mode is checked against the same fp32 expectation at bf16 resolution (2^-8 relative per operand)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+from oracle import brain_oracle as O   # noqa: E402
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from speech_decoding_amd import ops as _ops
+    from speech_decoding_amd import lib
+    lib.load()
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _ops
+
+
+def tol(dtype, k_terms=1):
+    if dtype == torch.float32:
+        return dict(rtol=2e-5, atol=2e-5)
+    return dict(rtol=2e-2, atol=2e-2 * math.sqrt(max(1, k_terms)) / 8)
+
+
+def to_rows(ops, x, dtype, Cp=None):
+    from speech_decoding_amd import lib as L
+    B, C, T = x.shape
+    buf = ops.new_rows(B, T, Cp or L.pad_channels(C), dtype, DEV)
+    ops.pack_rows(x.to(DEV), buf)
+    return buf
+
+
+def from_rows(ops, buf, B, C, T):
+    return ops.unpack_rows(buf, B, C, T).cpu()
+
+
+def rel_err(got, ref):
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+
+
+def q(x, dtype):
+    """quantise an fp32 tensor to the compute dtype (what the kernels will actually read)"""
+    return x.to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_unpack_roundtrip_and_padding(ops, dtype):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(0)
+    B, C, T = 3, 70, 150
+    x = torch.randn(B, C, T, generator=g)
+    buf = to_rows(ops, x, dtype)
+    back = from_rows(ops, buf, B, C, T)
+    assert torch.equal(back, q(x, dtype))
+    full = buf.float().cpu()
+    Tp = L.rows_tp(T)
+    valid = torch.zeros(full.shape[0], dtype=torch.bool)
+    for b in range(B):
+        valid[b * Tp + L.ROW_PAD: b * Tp + L.ROW_PAD + T] = True
+    assert float(full[~valid].abs().max()) == 0.0          # pad rows untouched
+    assert float(full[:, C:].abs().max()) == 0.0           # pad channels zero
+    view = ops.rows_view(buf, B, C, T).float().cpu()
+    assert torch.equal(view, q(x, dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,dil,T", [(40, 48, 1, 40), (270, 320, 2, 300), (320, 320, 16, 360),
+                                            (96, 128, 8, 130), (64, 640, 4, 129)])
+def test_conv3_forward_bias_residual_stats(ops, dtype, cin, cout, dil, T):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(cin + cout + dil)
+    B = 2
+    x = q(torch.randn(B, cin, T, generator=g), dtype)
+    w = q(torch.randn(cout, cin, 3, generator=g) / math.sqrt(3 * cin), dtype)
+    bias = torch.randn(cout, generator=g)
+    use_res = cin == cout
+    ref = TF.conv1d(x, w, bias, padding=dil, dilation=dil)
+    if use_res:
+        ref = ref + x
+    xb = to_rows(ops, x, dtype)
+    Cin_p, Cout_p = L.pad_channels(cin), L.pad_channels(cout)
+    wp = ops.pack_conv_weight(w.to(DEV), Cout_p, Cin_p, dtype)
+    yb = ops.new_rows(B, T, Cout_p, dtype, DEV)
+    stats = torch.zeros((B * ops.n_t_tiles(T), 2, Cout_p), device=DEV)
+    ops.conv_gemm(xb, wp, yb, B=B, T=T, KS=3, dil=dil, bias=ops.pack_vector(bias.to(DEV), Cout_p),
+                  res=xb if use_res else None, stats=stats)
+    got = from_rows(ops, yb, B, cout, T)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), **tol(dtype, 3 * cin))
+    # pad rows / channels of the output stay zero
+    full = yb.float().cpu()
+    if cout < Cout_p:
+        assert float(full[:, cout:].abs().max()) == 0.0
+    assert float(full[: L.ROW_PAD].abs().max()) == 0.0
+    # BatchNorm partial statistics: sums over valid rows of the stored values
+    s = stats.sum(dim=0).cpu()
+    np.testing.assert_allclose(s[0, :cout].numpy(), got.sum(dim=(0, 2)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[1, :cout].numpy(), (got ** 2).sum(dim=(0, 2)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv1_per_sample_weights_and_gelu(ops, dtype):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(3)
+    B, C, T, S = 5, 72, 200, 4
+    x = q(torch.randn(B, C, T, generator=g), dtype)
+    w = q(torch.randn(S, C, C, 1, generator=g) / math.sqrt(C), dtype)
+    idx = torch.tensor([2, 0, 3, 3, 1], dtype=torch.int32)
+    ref = torch.bmm(w[idx.long(), :, :, 0], x)
+    Cp = L.pad_channels(C)
+    xb = to_rows(ops, x, dtype)
+    wp = ops.pack_conv_weight(w.to(DEV), Cp, Cp, dtype)
+    yb = ops.new_rows(B, T, Cp, dtype, DEV)
+    ops.conv_gemm(xb, wp, yb, B=B, T=T, KS=1, dil=0, widx=idx.to(DEV))
+    np.testing.assert_allclose(from_rows(ops, yb, B, C, T).numpy(), ref.numpy(), **tol(dtype, C))
+    # GELU epilogue with the pre-activation saved
+    bias = torch.randn(C, generator=g)
+    w1 = w[0]
+    ref_pre = TF.conv1d(x, w1, bias)
+    pre, post = ops.new_rows(B, T, Cp, dtype, DEV), ops.new_rows(B, T, Cp, dtype, DEV)
+    ops.conv_gemm(xb, ops.pack_conv_weight(w1.to(DEV), Cp, Cp, dtype), post, B=B, T=T, KS=1, dil=0,
+                  bias=ops.pack_vector(bias.to(DEV), Cp), y_pre=pre, gelu=True)
+    np.testing.assert_allclose(from_rows(ops, pre, B, C, T).numpy(), ref_pre.numpy(), **tol(dtype, C))
+    np.testing.assert_allclose(from_rows(ops, post, B, C, T).numpy(), TF.gelu(ref_pre).numpy(), **tol(dtype, C))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,dil,T,glu", [(40, 48, 2, 70, False), (320, 320, 4, 200, False),
+                                                (64, 48, 2, 90, True), (320, 640, 2, 140, True)])
+def test_conv3_dgrad_and_wgrad(ops, dtype, cin, cout, dil, T, glu):
+    """dx via conv_gemm on mode-1 weights, dW via wgrad_gemm + reduce + unpack, vs torch autograd."""
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(cin * 3 + cout + dil)
+    B = 3
+    x = q(torch.randn(B, cin, T, generator=g), dtype).requires_grad_(True)
+    w = q(torch.randn(cout, cin, 3, generator=g) / math.sqrt(3 * cin), dtype).requires_grad_(True)
+    dy = q(torch.randn(B, cout, T, generator=g), dtype)
+    TF.conv1d(x, w, None, padding=dil, dilation=dil).backward(dy)
+    half = cout // 2 if glu else 0
+    half_p = L.pad_channels(half) if glu else 0
+    Cin_p = L.pad_channels(cin)
+    Cout_p = 2 * half_p if glu else L.pad_channels(cout)
+    # dy in the packed channel order (GLU layout splits the two halves at half_p)
+    dyb = ops.new_rows(B, T, Cout_p, dtype, DEV)
+    if glu:
+        tmp = torch.zeros(B, Cout_p, T)
+        tmp[:, :half] = dy[:, :half]
+        tmp[:, half_p: half_p + cout - half] = dy[:, half:]
+        ops.pack_rows(tmp.to(DEV), dyb)
+    else:
+        ops.pack_rows(dy.to(DEV), dyb)
+    xb = to_rows(ops, x.detach(), dtype)
+    wt = ops.pack_conv_weight(w.detach().to(DEV), Cout_p, Cin_p, dtype, mode=1, glu_half=half, glu_half_p=half_p)
+    dxb = ops.new_rows(B, T, Cin_p, dtype, DEV)
+    ops.conv_gemm(dyb, wt, dxb, B=B, T=T, KS=3, dil=dil)
+    np.testing.assert_allclose(from_rows(ops, dxb, B, cin, T).numpy(), x.grad.numpy(), **tol(dtype, 3 * cout))
+    perm = torch.tensor([2, 0, 1], dtype=torch.int32, device=DEV)
+    seg = torch.tensor([0, 1, 3], dtype=torch.int32, device=DEV)
+    slabs = ops.wgrad_gemm(dyb, xb, B=B, T=T, KS=3, dil=dil, perm=perm, seg_start=seg, nseg=2)
+    gw = ops.unpack_conv_wgrad(ops.reduce_slabs(slabs), 1, cout, cin, 3, Cout_p, Cin_p, half, half_p)[0].cpu()
+    np.testing.assert_allclose(gw.numpy(), w.grad.numpy(), **tol(dtype, B * T))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_per_subject_segments(ops, dtype):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(8)
+    B, C, T, S = 6, 80, 100, 4
+    x = q(torch.randn(B, C, T, generator=g), dtype)
+    dy = q(torch.randn(B, C, T, generator=g), dtype)
+    sidx = np.array([1, 3, 1, 0, 3, 3])
+    ref = torch.zeros(S, C, C)
+    for b in range(B):
+        ref[sidx[b]] += dy[b] @ x[b].T
+    order = np.argsort(sidx, kind="stable").astype(np.int32)
+    seg = np.searchsorted(sidx[order], np.arange(S + 1)).astype(np.int32)
+    Cp = L.pad_channels(C)
+    slabs = ops.wgrad_gemm(to_rows(ops, dy, dtype), to_rows(ops, x, dtype), B=B, T=T, KS=1, dil=0,
+                           perm=torch.from_numpy(order).to(DEV), seg_start=torch.from_numpy(seg).to(DEV), nseg=S)
+    got = ops.unpack_conv_wgrad(slabs, S, C, C, 1, Cp, Cp)[..., 0].cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), **tol(dtype, 3 * T))
+    assert float(got[2].abs().max()) == 0.0          # subject absent from the batch
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,T", [(24, 40), (320, 200)])
+def test_batchnorm_gelu_forward_backward(ops, dtype, C, T):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(C)
+    B = 4
+    x = q(torch.randn(B, C, T, generator=g) * 1.5 + 0.3, dtype).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.rand(C, generator=g) - 0.5).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    rm0, rv0 = rm.clone(), rv.clone()                      # torch updates rm/rv in place below
+    dy = q(torch.randn(B, C, T, generator=g), dtype)
+    y = TF.gelu(TF.batch_norm(x, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5))
+    y.backward(dy)
+    Cp = L.pad_channels(C)
+    xb = to_rows(ops, x.detach(), dtype)
+    # statistics through a 1x1 identity conv epilogue would be circular; build the partials directly
+    xs = ops.unpack_rows(xb, B, C, T)                      # stored (rounded) values, on device
+    part = torch.zeros((1, 2, Cp), device=DEV)
+    part[0, 0, :C] = xs.sum(dim=(0, 2))
+    part[0, 1, :C] = (xs ** 2).sum(dim=(0, 2))
+    rm_d, rv_d = rm0.to(DEV), rv0.to(DEV)
+    mean, rstd, scale, shift = ops.bn_finalize(part, 1, B * T, gamma.detach().to(DEV), beta.detach().to(DEV), rm_d, rv_d,
+                                               Cp, True)
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-5)     # torch updated rm/rv in place
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-5)
+    yb = ops.bn_gelu_forward(xb, ops.new_rows(B, T, Cp, dtype, DEV), scale, shift, B, T)
+    np.testing.assert_allclose(from_rows(ops, yb, B, C, T).numpy(), y.detach().numpy(), **tol(dtype))
+    dxb = ops.new_rows(B, T, Cp, dtype, DEV)
+    dgam, dbet = ops.bn_gelu_backward(to_rows(ops, dy, dtype), xb, mean, rstd, gamma.detach().to(DEV), beta.detach().to(DEV),
+                                      dxb, B, T, ops.reduce_scratch(Cp, DEV))
+    t = tol(dtype, B * T)
+    np.testing.assert_allclose(dgam[:C].cpu().numpy(), gamma.grad.numpy(), rtol=t["rtol"], atol=t["atol"])
+    np.testing.assert_allclose(dbet[:C].cpu().numpy(), beta.grad.numpy(), rtol=t["rtol"], atol=t["atol"])
+    np.testing.assert_allclose(from_rows(ops, dxb, B, C, T).numpy(), x.grad.numpy(), **tol(dtype, 4))
+    # eval mode: scale/shift from the running statistics
+    _, _, sc_e, sh_e = ops.bn_finalize(None, 0, B * T, gamma.detach().to(DEV), beta.detach().to(DEV), rm_d, rv_d, Cp, False)
+    ye = TF.gelu(TF.batch_norm(x.detach(), rm, rv, gamma.detach(), beta.detach(), training=False, eps=1e-5))
+    yb = ops.bn_gelu_forward(xb, ops.new_rows(B, T, Cp, dtype, DEV), sc_e, sh_e, B, T)
+    np.testing.assert_allclose(from_rows(ops, yb, B, C, T).numpy(), ye.numpy(), **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_glu_gelu_colsum(ops, dtype):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(5)
+    B, Ch, T = 3, 24, 77
+    Chp = L.pad_channels(Ch)
+    a = q(torch.randn(B, Ch, T, generator=g), dtype).requires_grad_(True)
+    gate = q(torch.randn(B, Ch, T, generator=g), dtype).requires_grad_(True)
+    dy = q(torch.randn(B, Ch, T, generator=g), dtype)
+    y = a * torch.sigmoid(gate)
+    y.backward(dy)
+    packed = torch.zeros(B, 2 * Chp, T)
+    packed[:, :Ch], packed[:, Chp: Chp + Ch] = a.detach(), gate.detach()
+    xb = to_rows(ops, packed, dtype, Cp=2 * Chp)
+    yb = ops.glu_forward(xb, ops.new_rows(B, T, Chp, dtype, DEV), B, T)
+    np.testing.assert_allclose(from_rows(ops, yb, B, Ch, T).numpy(), y.detach().numpy(), **tol(dtype))
+    dxb = ops.glu_backward(xb, to_rows(ops, dy, dtype), ops.new_rows(B, T, 2 * Chp, dtype, DEV), B, T)
+    dx = from_rows(ops, dxb, B, 2 * Chp, T)
+    np.testing.assert_allclose(dx[:, :Ch].numpy(), a.grad.numpy(), **tol(dtype))
+    np.testing.assert_allclose(dx[:, Chp: Chp + Ch].numpy(), gate.grad.numpy(), **tol(dtype))
+    # GELU backward + column sums
+    u = q(torch.randn(B, Ch, T, generator=g), dtype).requires_grad_(True)
+    TF.gelu(u).backward(dy)
+    du = ops.gelu_backward(to_rows(ops, u.detach(), dtype), to_rows(ops, dy, dtype), ops.new_rows(B, T, Chp, dtype, DEV), B, T)
+    np.testing.assert_allclose(from_rows(ops, du, B, Ch, T).numpy(), u.grad.numpy(), **tol(dtype))
+    cs = ops.colsum(to_rows(ops, dy, dtype), B, T, ops.reduce_scratch(Chp, DEV))
+    np.testing.assert_allclose(cs[:Ch].cpu().numpy(), dy.sum(dim=(0, 2)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_spatial_attention_weights_forward_backward(ops, dtype):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(2)
+    D1, K, C = 20, 6, 70
+    loc = O.synthetic_positions(C, seed=1)
+    cos, sin = O.fourier_tables(loc, K)
+    z = torch.complex(torch.rand(D1, K * K, generator=g), torch.rand(D1, K * K, generator=g)).requires_grad_(True)
+    mask = O.dropout_mask(loc, 5, 0.15)
+    P = {"subject_block.spatial_attention.z": z, "subject_block.spatial_attention.cos": cos,
+         "subject_block.spatial_attention.sin": sin}
+    W = O.sa_weights(P)
+    dWd = torch.randn(D1, C, generator=g)
+    (W * mask[None, :] * dWd).sum().backward()
+    D1p, Cp = L.pad_channels(D1), L.pad_channels(C)
+    Wg, Wp = ops.sa_weights_forward(z.detach().to(DEV), cos.to(DEV), sin.to(DEV), mask.to(DEV), D1p, Cp, dtype)
+    np.testing.assert_allclose(Wg.cpu().numpy(), W.detach().numpy(), rtol=2e-4, atol=1e-7)
+    wp = Wp.float().cpu()[0, 0]
+    np.testing.assert_allclose(wp[:D1, :C].numpy(), q(W.detach() * mask[None, :], dtype).numpy(), rtol=1e-2 if dtype != torch.float32 else 2e-4, atol=1e-6)
+    assert float(wp[D1:].abs().max()) == 0.0 and float(wp[:, C:].abs().max()) == 0.0
+    dpad = torch.zeros(D1p, Cp)
+    dpad[:D1, :C] = dWd
+    dz = ops.sa_weights_backward(dpad.to(DEV), Wg, mask.to(DEV), cos.t().contiguous().to(DEV), sin.t().contiguous().to(DEV), K * K)
+    ref = z.grad
+    np.testing.assert_allclose(torch.view_as_real(dz.cpu()).numpy(), torch.view_as_real(ref).numpy(), rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,F,T", [(6, 32, 40), (24, 64, 100), (130, 64, 20)])
+def test_clip_loss_forward_backward_and_ranks(ops, dtype, B, F, T):
+    from speech_decoding_amd import engine as E, lib as L
+    g = torch.Generator().manual_seed(B)
+    Y = q(torch.randn(B, F, T, generator=g), dtype)
+    Z = q(0.3 * Y + torch.randn(B, F, T, generator=g), dtype).requires_grad_(True)
+    temp = torch.tensor([2.0], requires_grad=True)
+    loss, logits = O.clip_loss(Y, Z, temp)
+    loss.backward()
+    Yt, Zt = to_rows(ops, Y, dtype), to_rows(ops, Z.detach(), dtype)
+    lg, lgts, cnt, ctx = E.clip_forward(Yt, Zt, temp.detach().to(DEV), Bm=B, Bn=B, T=T)
+    lt = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(lgts.cpu().numpy(), logits.detach().numpy(), **lt)
+    assert abs(float(lg) - float(loss)) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert abs(float(ctx.dtemp) - float(temp.grad)) < (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, abs(float(temp.grad)))
+    dZt = ops.new_rows(B, T, L.pad_channels(F), dtype, DEV)
+    E.clip_backward(ctx, dZt)
+    dz = from_rows(ops, dZt, B, F, T)
+    scale = float(Z.grad.abs().max())
+    assert float((dz - Z.grad).abs().max()) <= (2e-4 if dtype == torch.float32 else 3e-2) * scale
+    # retrieval ranks against a direct count on the oracle logits
+    sim = logits.detach()
+    want = (sim > sim.diag()[:, None]).sum(dim=1)
+    if dtype == torch.float32:
+        assert torch.equal(cnt.cpu().long(), want)
+    else:
+        assert (cnt.cpu().long() - want).abs().max() <= 1
