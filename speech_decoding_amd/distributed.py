@@ -63,3 +63,16 @@ def shard_range(n: int, rank: int, world: int):
     """Contiguous shard [lo, hi) of n samples for `rank` (global sample order = rank-major)."""
     per = n // world
     return rank * per, (rank + 1) * per
+
+
+def merge_row_softmax_stats(row_max: torch.Tensor, row_sum: torch.Tensor, group=None):
+    """Each rank holds, for every GLOBAL speech row, (max, sum exp(l - max)) over ITS OWN block of brain
+    columns.  Returns the row-wise log-sum-exp over all columns of all ranks (2 small all-reduces):
+        M = max_r m_r ;  S = sum_r s_r * exp(m_r - M) ;  lse = M + log S."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        gmax = row_max.clone()
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+        row_sum = row_sum * torch.exp(row_max - gmax)
+        dist.all_reduce(row_sum, op=dist.ReduceOp.SUM, group=group)
+        row_max = gmax
+    return row_max + torch.log(row_sum)

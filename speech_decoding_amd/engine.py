@@ -327,14 +327,10 @@ def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: 
     zsq = ops.rows_sumsq(Zt, Bn, row_elems, row_elems)
     S = ops.matmul_nt_splitk(Yt, Zt, Bm, Bn, row_elems, row_elems)
     logits, row_max, row_sum, col_lse, diag = ops.clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0)
+    from .distributed import merge_row_softmax_stats
     if dist_group is not None and dist.get_world_size(dist_group) > 1:
-        gmax = row_max.clone()
-        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=dist_group)
-        row_sum = row_sum * torch.exp(row_max - gmax)
-        dist.all_reduce(row_sum, op=dist.ReduceOp.SUM, group=dist_group)
         dist.all_reduce(diag, op=dist.ReduceOp.SUM, group=dist_group)     # zero where not owned
-        row_max = gmax
-    row_lse = row_max + torch.log(row_sum)
+    row_lse = merge_row_softmax_stats(row_max, row_sum, dist_group)
     Bg = B_global if B_global is not None else Bm
     inv_norm = 1.0 / (2.0 * Bg) if reduction == "mean" else 0.5
     G, rscale, scalars = ops.clip_grad(logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, Yt.dtype)

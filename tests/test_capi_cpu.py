@@ -1,0 +1,105 @@
+"""CPU checks of the drop-in boundary: libsdamd.so loads, exports every symbol include/sd_amd.h declares,
+the ctypes mirror of the argument structs matches the C layout, and the product refuses to run without
+a GPU (no silent CPU fallback).  No kernel is launched here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sd_amd.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from speech_decoding_amd import lib as L
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return L
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sda_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = declared_symbols()
+    assert len(names) >= 30
+    cdll = ctypes.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(cdll, n), f"{n} declared in sd_amd.h but not exported"
+        assert n in lib.SIGNATURES, f"{n} has no ctypes signature in lib.py"
+    assert set(lib.SIGNATURES) == set(names)
+    L = lib.load()
+    assert L.sda_abi_version() == 1
+
+
+def test_layout_helpers_agree_with_python_mirror(lib):
+    L = lib.load()
+    for B, T in [(1, 1), (6, 40), (256, 360), (512, 1000)]:
+        assert L.sda_rows_alloc(B, T) == lib.rows_alloc(B, T)
+    for c in (1, 60, 64, 208, 270, 306, 1024):
+        assert L.sda_pad_channels(c) == lib.pad_channels(c)
+    assert L.sda_conv_n_t_tiles(360) == 3 and L.sda_conv_n_t_tiles(128) == 1
+
+
+def test_struct_layout_matches_c(lib, tmp_path):
+    """sizeof/offsetof of the two argument structs as the C compiler sees them vs the ctypes mirror."""
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sd_amd.h"\nint main(void){\n'
+                   'printf("%zu %zu %zu %zu %zu\\n", sizeof(sda_conv_args), offsetof(sda_conv_args, B), '
+                   'offsetof(sda_conv_args, x_pitch), offsetof(sda_conv_args, w_rows_limit), offsetof(sda_conv_args, dtype));\n'
+                   'printf("%zu %zu %zu %zu %zu\\n", sizeof(sda_wgrad_args), offsetof(sda_wgrad_args, nseg), '
+                   'offsetof(sda_wgrad_args, dy_pitch), offsetof(sda_wgrad_args, rows_limit), offsetof(sda_wgrad_args, dtype));\n'
+                   'return 0;}\n')
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    ca, wa = lib.ConvArgs, lib.WgradArgs
+    assert [int(v) for v in out[0].split()] == [ctypes.sizeof(ca), ca.B.offset, ca.x_pitch.offset,
+                                                ca.w_rows_limit.offset, ca.dtype.offset]
+    assert [int(v) for v in out[1].split()] == [ctypes.sizeof(wa), wa.nseg.offset, wa.dy_pitch.offset,
+                                                wa.rows_limit.offset, wa.dtype.offset]
+
+
+def test_argument_validation_without_launch(lib):
+    L = lib.load()
+    a = lib.ConvArgs()
+    assert L.sda_conv_gemm(ctypes.byref(a), None) == -1
+    assert b"null" in L.sda_last_error()
+    w = lib.WgradArgs()
+    assert L.sda_wgrad_gemm(ctypes.byref(w), None) == -1
+    assert L.sda_pack_rows(None, None, 1, 1, 1, 64, 0, None) == -1
+
+
+def test_product_fails_loudly_without_gpu_or_library(lib, monkeypatch, tmp_path):
+    from speech_decoding_amd import SdaError
+    from speech_decoding.models import BrainEncoder
+    from speech_decoding_amd import load_config
+    import warnings
+    cfg = load_config(overrides=["num_subjects=2", "D1=8", "D2=8", "F=8", "K=2", "preprocs.last4layers=False", "num_channels=6"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc = BrainEncoder(cfg)
+    if not torch.cuda.is_available():
+        with pytest.raises(SdaError):
+            enc(torch.randn(3, 6, 20), torch.zeros(3, dtype=torch.int32))
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(SdaError):
+        lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "speech_decoding_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"

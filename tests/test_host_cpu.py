@@ -1,0 +1,109 @@
+"""Host-side logic that needs no GPU: config surface, parameter containers / state_dict compatibility,
+initialisation order, sensor layout normalisation, segment construction."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import brain_oracle as O
+from tests import golden_io as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def small_cfg(**kw):
+    from speech_decoding_amd import load_config
+    ov = ["num_subjects=3", "D1=16", "D2=24", "F=32", "K=4", "preprocs.last4layers=False", "num_channels=12"]
+    ov += [f"{k}={v}" for k, v in kw.items()]
+    return load_config(overrides=ov)
+
+
+def test_config_surface_matches_reference_keys():
+    from speech_decoding_amd import load_config
+    cfg = load_config()
+    for key in ["dataset", "rebuild_dataset", "use_wandb", "wandb", "use_sampler", "reproducible", "split_ratio",
+                "split_mode", "num_workers", "batch_size", "updates", "lr", "epochs", "reduction", "D1", "D2", "F",
+                "K", "d_drop", "init_temperature", "wav2vec_model", "preprocs", "memory_efficient", "hydra"]:
+        assert key in cfg, key
+    assert (cfg.D1, cfg.D2, cfg.F, cfg.K, cfg.d_drop, cfg.init_temperature) == (270, 320, 512, 32, 0.1, 5.1)
+    assert cfg.preprocs["last4layers"] is True and cfg.preprocs.clamp_lim == 20       # item and attribute access
+    assert float(cfg.lr) == 3e-4 and cfg.hydra.job.chdir is True
+    cfg2 = load_config(overrides=["dataset=Brennan2018", "preprocs.clamp_lim=10", "+num_subjects=5"])
+    assert cfg2.dataset == "Brennan2018" and cfg2.preprocs.clamp_lim == 10 and cfg2.num_subjects == 5
+    with pytest.raises(ValueError):
+        load_config(overrides=["nonsense"])
+
+
+def test_state_dict_keys_shapes_and_roundtrip():
+    from speech_decoding.models import BrainEncoder
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc = BrainEncoder(small_cfg())
+    shapes = O.param_shapes(12, 3, 16, 24, 32, 4)
+    sd = enc.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    for k, (shape, kind) in shapes.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+        assert sd[k].is_complex() == (kind == "complex")
+    small = G.load("e2e_small.npz")
+    ref_state = G.state_from(small, "init/")
+    ref_state.pop("temp")
+    missing, unexpected = enc.load_state_dict(ref_state, strict=True)
+    assert not missing and not unexpected
+    back = enc.state_dict()
+    for k, v in ref_state.items():
+        assert torch.equal(back[k], v), k
+    bad = dict(ref_state)
+    bad["subject_block.subject_layer.7.weight"] = bad["subject_block.subject_layer.0.weight"]
+    with pytest.raises(RuntimeError):
+        enc.load_state_dict(bad, strict=True)
+    n_real = sum(p.numel() * (2 if p.is_complex() else 1) for p in enc.parameters())
+    assert n_real == sum(int(np.prod(s)) * (2 if kd == "complex" else 1) for s, kd in shapes.values() if kd != "buffer")
+
+
+def test_full_size_parameter_count_matches_survey():
+    """9,565,054 real parameters at C=208 (any C), S=27."""
+    shapes = O.param_shapes(208, 27, 270, 320, 1024, 32)
+    n = sum(int(np.prod(s)) * (2 if kd == "complex" else 1) for s, kd in shapes.values() if kd != "buffer")
+    assert n == 9_565_054
+
+
+def test_spatial_dropout_mask_and_tables_follow_reference_formulas():
+    from speech_decoding_amd.models import SpatialAttention
+    cfg = small_cfg()
+    loc = O.synthetic_positions(12, seed=7)
+    cfg["sensor_positions"] = loc.numpy()
+    sa = SpatialAttention(cfg)
+    cos, sin = O.fourier_tables(sa.loc, 4)
+    assert torch.allclose(sa.cos, cos, atol=1e-6) and torch.allclose(sa.sin, sin, atol=1e-6)
+    for centre in range(12):
+        assert torch.equal(sa.mask_for(centre), O.dropout_mask(sa.loc, centre, 0.1))
+    np.random.seed(5)
+    expect = int(np.random.randint(12))
+    np.random.seed(5)
+    assert torch.equal(sa.draw_mask(), sa.mask_for(expect))          # NumPy global RNG, one draw (models.py:81)
+    assert sa.z.dtype == torch.complex64 and float(sa.z.real.min()) >= 0 and float(sa.z.imag.max()) < 1
+
+
+def test_layout_normalisation():
+    from speech_decoding_amd.layout import normalise
+    raw = np.random.RandomState(0).rand(30, 2) * 7 - 3
+    out = normalise(raw)
+    assert out.dtype == torch.float32
+    assert float(out.min()) == pytest.approx(0.1) and float(out.max()) == pytest.approx(0.9)
+    assert torch.allclose(out, O.normalise_positions(raw))
+
+
+def test_uniform_and_subject_segments():
+    from speech_decoding_amd.engine import EncoderDims, EncoderEngine, block_dilations
+    assert [block_dilations(k) for k in range(5)] == [(1, 2, 2), (4, 8, 2), (16, 1, 2), (2, 4, 2), (8, 16, 2)]
+    eng = EncoderEngine(EncoderDims(208, 27, 270, 320, 1024, 32))
+    for B, ntiles in [(256, 10), (7, 1), (256, 80), (3, 1000)]:
+        perm, seg, nseg = eng._uniform_segments(B, ntiles, "cpu")
+        seg = seg.numpy()
+        assert seg[0] == 0 and seg[-1] == B and len(seg) == nseg + 1 and (np.diff(seg) >= 0).all()
+        assert torch.equal(perm, torch.arange(B, dtype=torch.int32))
+    d = eng.d
+    assert (d.Cp, d.D1p, d.D2p, d.F1p, d.Fp) == (256, 320, 320, 640, 1024)
