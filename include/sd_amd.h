@@ -113,8 +113,8 @@ int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const float* mean
                                 float* dbeta, int B, int T, int Cp, int dtype, void* stream);
 int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean, const float* rstd,
                                const float* gamma, const float* beta, int C, const float* dgamma,
-                               const float* dbeta, double count, void* dx, int B, int T, int Cp, int dtype,
-                               void* stream);
+                               const float* dbeta, double count, float* coef /* 6*Cp floats scratch */, void* dx,
+                               int B, int T, int Cp, int dtype, void* stream);
 int sda_reduce_scratch_floats(int Cp);
 
 /* GLU over channels: y[:, c] = x[:, c] * sigmoid(x[:, Ch + c]), x has 2*Ch channels (models.py:164) */

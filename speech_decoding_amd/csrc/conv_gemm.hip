@@ -16,33 +16,54 @@
 
 namespace sda {
 
-constexpr int XS_BYTES = (TILE_T + 2 * PAD) * 128;
+// One LDS row = one MFMA K-step = 64 bytes (32 bf16 / 16 fp32 input channels).
+constexpr int ROW_B = 64;
+constexpr int XROWS = TILE_T + 2 * PAD;            // 160: worst-case halo
+constexpr int XS_BYTES = XROWS * ROW_B;            // 10 KB
 constexpr int EP_ROWS = 64;
 
 template <int TILE_CO> struct EpiGeom {
   static constexpr int STRIDE = TILE_CO + 4;          // floats; == 4 (mod 8): conflict-free D writes
   static constexpr int NCH = TILE_CO / 4;             // 4-channel chunks per row
   static constexpr int RG = 256 / NCH;                // row groups
+  static constexpr int ITERS = (EP_ROWS + RG - 1) / RG;
   static constexpr int EP_BYTES = EP_ROWS * STRIDE * 4;
   static constexpr int RED_BYTES = RG * TILE_CO * 2 * 4;
 };
 
+template <int TILE_CO, int KS> constexpr int conv_stage_bytes() { return XS_BYTES + KS * TILE_CO * ROW_B; }
 template <int TILE_CO, int KS> constexpr int conv_lds_bytes() {
-  constexpr int main_b = XS_BYTES + KS * TILE_CO * 128;
+  constexpr int main_b = 2 * conv_stage_bytes<TILE_CO, KS>();
   constexpr int epi_b = EpiGeom<TILE_CO>::EP_BYTES + EpiGeom<TILE_CO>::RED_BYTES;
   return main_b > epi_b ? main_b : epi_b;
+}
+
+// 64-byte rows, 4 chunks of 16 bytes: chunk' = chunk ^ ((row >> 2) & 3) makes 16 consecutive rows read at
+// the same logical chunk (the MFMA operand pattern) land on 16 distinct 16-byte slots of the bank row.
+__device__ inline int lds_sw64(int row, int chunk) { return row * ROW_B + (((chunk ^ (row >> 2)) & 3) << 4); }
+
+typedef __attribute__((address_space(1))) const void gmem_cv;
+typedef __attribute__((address_space(3))) void lds_v;
+
+template <typename T> __device__ inline float4 round_like(float4 v);
+template <> __device__ inline float4 round_like<float>(float4 v) { return v; }
+template <> __device__ inline float4 round_like<uint16_t>(float4 v) {
+  return make_float4(bf2f(f2bf(v.x)), bf2f(f2bf(v.y)), bf2f(f2bf(v.z)), bf2f(f2bf(v.w)));
 }
 
 template <typename E, int TILE_CO, int KS>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a, const int n_t_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int SLAB = Elem<E>::SLAB;
+  constexpr int SLAB = ROW_B / (int)sizeof(E);          // input channels per LDS row / K-step
   constexpr int PER16 = Elem<E>::PER16;
   constexpr int NREP = TILE_CO / 32;
   constexpr int HALF_CO = TILE_CO / 2;
+  constexpr int STAGE = conv_stage_bytes<TILE_CO, KS>();
+  constexpr int W_PIECES = KS * TILE_CO / 16;           // 1 KB pieces = 16 rows x 64 B
   using G = EpiGeom<TILE_CO>;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_t = wid >> 1, wave_c = wid & 1;
   const int lr = lane & 15, lq = lane >> 4;
 
@@ -61,10 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
   const int wsel = a.widx ? a.widx[b] : 0;
   const E* __restrict__ wg = reinterpret_cast<const E*>(a.w) + (size_t)wsel * KS * a.Cout_p * a.w_pitch;
   const long row_base = a.x_row0 + (long)b * a.x_sample_rows + t0 - halo;   // LDS x row 0
-  const int NX = TILE_T + 2 * halo;
-
-  unsigned char* xs = smem;
-  unsigned char* ws = smem + XS_BYTES;
+  const int x_pieces = (TILE_T + 2 * halo + 15) >> 4;                       // 16-row pieces actually needed
 
   f32x4 acc[4][NREP];
 #pragma unroll
@@ -75,48 +93,61 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
   const int nslab = a.Cin_p / SLAB;
   const int per_split = (nslab + a.ksplit - 1) / a.ksplit;
   const int s_begin = ks * per_split;
-  const int s_end = min(nslab, s_begin + per_split);
+  const int s_end = (a.flags & 512) ? s_begin : min(nslab, s_begin + per_split);
 
-  for (int s = s_begin; s < s_end; ++s) {
-    __syncthreads();
-    // ---- stage the input slab: NX rows x 128 bytes
-    for (int idx = tid; idx < NX * 8; idx += 256) {
-      const int r = idx >> 3, c = idx & 7;
-      const long row = row_base + r;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (row >= 0 && row < a.x_rows_limit)
-        v = *reinterpret_cast<const uint4*>(xg + (size_t)row * a.x_pitch + (size_t)s * SLAB + c * PER16);
-      *reinterpret_cast<uint4*>(xs + lds_sw(r, c)) = v;
+  // Per-lane source offsets of the LDS-DMA pieces.  A piece is one wave-instruction: 64 lanes x 16 B land
+  // lane-linearly in LDS (16 rows x 64 B), so the swizzle goes on the SOURCE chunk.  Rows outside the
+  // operand (only possible in split-K matrix mode) are clamped: they feed outputs that are never stored.
+  const int prow = lane >> 2;                                   // row within the piece
+  const int pchunk = lane & 3;                                  // physical chunk written by this lane
+  auto stage = [&](int s, int buf) {
+    unsigned char* xs = smem + buf * STAGE;
+    unsigned char* ws = xs + XS_BYTES;
+    const size_t koff = (size_t)s * SLAB;
+    for (int p = wid; p < x_pieces; p += 4) {
+      const int r = p * 16 + prow;
+      long row = row_base + r;
+      row = row < 0 ? 0 : (row >= a.x_rows_limit ? a.x_rows_limit - 1 : row);
+      const int lc = (pchunk ^ (r >> 2)) & 3;
+      __builtin_amdgcn_global_load_lds((gmem_cv*)(xg + (size_t)row * a.x_pitch + koff + lc * PER16),
+                                       (lds_v*)(xs + p * 1024), 16, 0, 0);
     }
-    // ---- stage the weight slab: KS x TILE_CO rows x 128 bytes
-    for (int idx = tid; idx < KS * TILE_CO * 8; idx += 256) {
-      const int r = idx >> 3, c = idx & 7;
-      const int tap = r / TILE_CO, co = r - tap * TILE_CO;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (co0 + co < a.w_rows_limit)
-        v = *reinterpret_cast<const uint4*>(wg + ((size_t)tap * a.Cout_p + co0 + co) * a.w_pitch +
-                                            (size_t)s * SLAB + c * PER16);
-      *reinterpret_cast<uint4*>(ws + lds_sw(r, c)) = v;
-    }
-    __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int tap = 0; tap < KS; ++tap) {
-        uint4 af[4], bf[NREP];
-        const int xrow = wave_t * 64 + lr + tap * dil;
-        const int wrow = tap * TILE_CO + wave_c * HALF_CO + lr;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          af[m] = *reinterpret_cast<const uint4*>(xs + lds_sw(xrow + m * 16, kk * 4 + lq));
-#pragma unroll
-        for (int n = 0; n < NREP; ++n)
-          bf[n] = *reinterpret_cast<const uint4*>(ws + lds_sw(wrow + n * 16, kk * 4 + lq));
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af[m], bf[n], acc[m][n]);
+    for (int i = 0; i < (W_PIECES + 3) / 4; ++i) {
+      const int p = wid + i * 4;
+      if (p < W_PIECES) {
+        const int r = p * 16 + prow;                            // row of the [tap][co] weight image
+        const int tap = r / TILE_CO;
+        int co = co0 + (r - tap * TILE_CO);
+        co = co < a.w_rows_limit ? co : a.w_rows_limit - 1;
+        const int lc = (pchunk ^ (r >> 2)) & 3;
+        __builtin_amdgcn_global_load_lds((gmem_cv*)(wg + ((size_t)tap * a.Cout_p + co) * a.w_pitch + koff + lc * PER16),
+                                         (lds_v*)(ws + p * 1024), 16, 0, 0);
       }
+    }
+  };
+
+  if (s_begin < s_end) stage(s_begin, 0);
+  for (int s = s_begin; s < s_end; ++s) {
+    const int cur = (s - s_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of slab s have landed
+    __syncthreads();                                    // ... everybody's have, and slab s-1 is fully consumed
+    if (s + 1 < s_end) stage(s + 1, cur ^ 1);           // DMA of the next slab overlaps the MFMAs below
+    const unsigned char* xs = smem + cur * STAGE;
+    const unsigned char* ws = xs + XS_BYTES;
+#pragma unroll
+    for (int tap = 0; tap < KS; ++tap) {
+      uint4 af[4], bf[NREP];
+      const int xrow = wave_t * 64 + lr + tap * dil;
+      const int wrow = tap * TILE_CO + wave_c * HALF_CO + lr;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow + m * 16, lq));
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) bf[n] = *reinterpret_cast<const uint4*>(ws + lds_sw64(wrow + n * 16, lq));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af[m], bf[n], acc[m][n]);
     }
   }
 
@@ -137,6 +168,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
   }
 
   // ------------------------------------------------------------------ epilogue
+  if (a.flags & 256) {        // diagnostic: skip the epilogue, keep the accumulators live
+    float keep = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) keep += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    if (keep == 123.456f) reinterpret_cast<float*>(a.y)[0] = keep;
+    return;
+  }
   if (a.bias) {
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
@@ -158,6 +198,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
   const long out_row0 = a.x_row0 + (long)b * a.x_sample_rows + t0;
 
   for (int h = 0; h < 2; ++h) {
+    // residual rows of this half: issue all loads up front so their latency hides behind the LDS staging
+    float4 rv[G::ITERS];
+    if (resg && active) {
+#pragma unroll
+      for (int it = 0; it < G::ITERS; ++it) {
+        const int row = rg + it * G::RG;
+        rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < EP_ROWS && t0 + h * EP_ROWS + row < a.T)
+          rv[it] = load4(resg + (size_t)(out_row0 + h * EP_ROWS + row) * a.Cout_p + co0 + chunk * 4);
+      }
+    }
     __syncthreads();            // main-loop LDS reads (h == 0) / previous half's reads are done
     if (wave_t == h) {
 #pragma unroll
@@ -170,25 +221,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
     }
     __syncthreads();
     if (active) {
-      for (int row = rg; row < EP_ROWS; row += G::RG) {
+#pragma unroll
+      for (int it = 0; it < G::ITERS; ++it) {
+        const int row = rg + it * G::RG;
         const int t = t0 + h * EP_ROWS + row;
-        if (t >= a.T) break;
-        float4 v = *reinterpret_cast<const float4*>(ep + row * G::STRIDE + chunk * 4);
-        const size_t off = (size_t)(out_row0 + h * EP_ROWS + row) * a.Cout_p + co0 + chunk * 4;
-        if (resg) {
-          const float4 rv = load4(resg + off);
-          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-        }
-        if (a.flags & SDA_EPI_GELU) {
-          if (ypre) store4(ypre + off, v);
-          v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
-        }
-        store4(yg + off, v);
-        if (a.stats) {
-          // statistics of the values as stored (rounded to E), so BN normalises what it will read
-          const float4 q = load4(yg + off);
-          ssum[0] += q.x; ssum[1] += q.y; ssum[2] += q.z; ssum[3] += q.w;
-          ssq[0] += q.x * q.x; ssq[1] += q.y * q.y; ssq[2] += q.z * q.z; ssq[3] += q.w * q.w;
+        if (row < EP_ROWS && t < a.T) {
+          float4 v = *reinterpret_cast<const float4*>(ep + row * G::STRIDE + chunk * 4);
+          const size_t off = (size_t)(out_row0 + h * EP_ROWS + row) * a.Cout_p + co0 + chunk * 4;
+          if (resg) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+          if (a.flags & SDA_EPI_GELU) {
+            if (ypre) store4(ypre + off, v);
+            v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+          }
+          store4(yg + off, v);
+          if (a.stats) {
+            // statistics of the values as stored (rounded to E), so BN normalises what it will read
+            const float4 q = round_like<E>(v);
+            ssum[0] += q.x; ssum[1] += q.y; ssum[2] += q.z; ssum[3] += q.w;
+            ssq[0] += q.x * q.x; ssq[1] += q.y * q.y; ssq[2] += q.z * q.z; ssq[3] += q.w * q.w;
+          }
         }
       }
     }

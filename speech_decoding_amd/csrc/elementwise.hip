@@ -137,15 +137,16 @@ __global__ void unpack_vector_kernel(const float* __restrict__ g, float* __restr
 // ------------------------------------------------------------------------------------------------
 // BatchNorm1d: finalize / apply+GELU / backward   (models.py:135,143,158,161)
 // ------------------------------------------------------------------------------------------------
-// Sum partial[k][which][c] over k for the 32 channels of this block: 8 thread groups stride over k,
-// fp64 accumulation, fixed combination order (deterministic).  Result valid for threadIdx.x < 32.
+// Sum partial[k][which][c] over k for the 16 channels of this block: 16 thread groups stride over k,
+// fp64 accumulation, fixed combination order (deterministic).  Result valid for threadIdx.x < 16.
 __device__ inline void block_partial_sums(const float* __restrict__ partial, int n, int Cp, int c, bool two,
                                           double& s0, double& s1) {
-  __shared__ double sh[2][8][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  __shared__ double sh[2][16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   double a0 = 0.0, a1 = 0.0;
   if (c < Cp) {
-    for (int k = ty; k < n; k += 8) {
+#pragma unroll 4
+    for (int k = ty; k < n; k += 16) {
       a0 += (double)partial[((size_t)k * 2 + 0) * Cp + c];
       if (two) a1 += (double)partial[((size_t)k * 2 + 1) * Cp + c];
     }
@@ -156,7 +157,7 @@ __device__ inline void block_partial_sums(const float* __restrict__ partial, int
   s0 = 0.0; s1 = 0.0;
   if (ty == 0) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) { s0 += sh[0][g][tx]; s1 += sh[1][g][tx]; }
+    for (int g = 0; g < 16; ++g) { s0 += sh[0][g][tx]; s1 += sh[1][g][tx]; }
   }
 }
 
@@ -164,10 +165,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* mean_o,
                                    float* rstd_o, float* scale_o, float* shift_o, int C, int Cp, int training) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   double s = 0.0, q = 0.0;
   if (training) block_partial_sums(partial, ntiles, Cp, c, true, s, q);
-  if (threadIdx.x >= 32 || c >= Cp) return;
+  if (threadIdx.x >= 16 || c >= Cp) return;
   if (c >= C) { mean_o[c] = 0.f; rstd_o[c] = 0.f; scale_o[c] = 0.f; shift_o[c] = 0.f; return; }
   double mean, var;
   if (training) {
@@ -279,21 +280,34 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
 // sums[which][c] = sum over blocks (fp64, fixed order)
 __global__ __launch_bounds__(256) void col_reduce_final_kernel(const float* __restrict__ partial, int nblocks,
                                                                float* __restrict__ out0, float* __restrict__ out1, int Cp) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   double s0, s1;
   block_partial_sums(partial, nblocks, Cp, c, out1 != nullptr, s0, s1);
-  if (threadIdx.x >= 32 || c >= Cp) return;
+  if (threadIdx.x >= 16 || c >= Cp) return;
   out0[c] = (float)s0;
   if (out1) out1[c] = (float)s1;
 }
 
+// per-channel coefficients of the BN+GELU backward, precomputed once per launch into a [6][Cp] table:
+//   0: gamma  1: beta  2: mean  3: rstd  4: dbeta/N  5: dgamma/N
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                   const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_count,
+                                   float* __restrict__ coef, int Cp) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  coef[0 * Cp + c] = c < C ? gamma[c] : 0.f;
+  coef[1 * Cp + c] = c < C ? beta[c] : 0.f;
+  coef[2 * Cp + c] = mean[c];
+  coef[3 * Cp + c] = rstd[c];
+  coef[4 * Cp + c] = dbeta[c] * inv_count;
+  coef[5 * Cp + c] = dgamma[c] * inv_count;
+}
+
 template <typename E>
 __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restrict__ dy, const E* __restrict__ x,
-                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                int C, const float* __restrict__ dbeta,
-                                                                const float* __restrict__ dgamma, float inv_count,
-                                                                E* __restrict__ dx, int B, int T, int Cp) {
+                                                                const float* __restrict__ coef, E* __restrict__ dx,
+                                                                int B, int T, int Cp) {
   const int nch = Cp / 4;
   const size_t total = (size_t)B * T * nch;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -302,17 +316,22 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restr
     const int b = vr / T, t = vr - (size_t)b * T;
     const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
     const float4 d4 = load4(dy + off), x4 = load4(x + off);
-    const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
-    float o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = ch * 4 + j;
-      const float ga = c < C ? gamma[c] : 0.f, be = c < C ? beta[c] : 0.f;
-      const float xh = (xv[j] - mean[c]) * rstd[c];
-      const float dg = dv[j] * gelu_grad_f(ga * xh + be);
-      o[j] = ga * rstd[c] * (dg - dbeta[c] * inv_count - xh * dgamma[c] * inv_count);
+    const float4 ga = *reinterpret_cast<const float4*>(coef + 0 * Cp + ch * 4);
+    const float4 be = *reinterpret_cast<const float4*>(coef + 1 * Cp + ch * 4);
+    const float4 mu = *reinterpret_cast<const float4*>(coef + 2 * Cp + ch * 4);
+    const float4 rs = *reinterpret_cast<const float4*>(coef + 3 * Cp + ch * 4);
+    const float4 db = *reinterpret_cast<const float4*>(coef + 4 * Cp + ch * 4);
+    const float4 dg = *reinterpret_cast<const float4*>(coef + 5 * Cp + ch * 4);
+    float4 o;
+#define SDA_BN_BWD(f)                                          \
+    {                                                          \
+      const float xh = (x4.f - mu.f) * rs.f;                   \
+      const float g = d4.f * gelu_grad_f(ga.f * xh + be.f);    \
+      o.f = ga.f * rs.f * (g - db.f - xh * dg.f);              \
     }
-    store4(dx + off, make_float4(o[0], o[1], o[2], o[3]));
+    SDA_BN_BWD(x) SDA_BN_BWD(y) SDA_BN_BWD(z) SDA_BN_BWD(w)
+#undef SDA_BN_BWD
+    store4(dx + off, o);
   }
 }
 
@@ -473,7 +492,7 @@ extern "C" int sda_bn_finalize(const float* partial, int ntiles, double count, c
   if (!gamma || !beta || !mean || !rstd || !scale || !shift || C > Cp) { set_error("bn_finalize: bad arguments"); return -1; }
   if (training && (!partial || ntiles < 1 || count < 1.0)) { set_error("bn_finalize: training mode needs partial statistics"); return -1; }
   if (!training && (!running_mean || !running_var)) { set_error("bn_finalize: eval mode needs running statistics"); return -1; }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, ntiles, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, ntiles, count,
                      gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, C, Cp, training);
   return check_launch("bn_finalize");
 }
@@ -501,22 +520,24 @@ extern "C" int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const 
   const size_t lds = (size_t)RG * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((col_reduce_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)dy,
                                          (const E*)x, mean, rstd, gamma, beta, C, partial, B, T, Cp));
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 31) / 32), dim3(256), 0, st, partial, nb, dbeta, dgamma, Cp);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 15) / 16), dim3(256), 0, st, partial, nb, dbeta, dgamma, Cp);
   return check_launch("bn_gelu_backward_reduce");
 }
 
 extern "C" int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean, const float* rstd,
                                           const float* gamma, const float* beta, int C, const float* dgamma,
-                                          const float* dbeta, double count, void* dx, int B, int T, int Cp, int dtype,
-                                          void* stream) {
-  if (!dy || !x || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !dx || Cp % 64 || count < 1.0) {
+                                          const float* dbeta, double count, float* coef, void* dx, int B, int T, int Cp,
+                                          int dtype, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !coef || !dx || Cp % 64 || count < 1.0) {
     set_error("bn_gelu_backward_apply: bad arguments"); return -1;
   }
   const size_t total = (size_t)B * T * (Cp / 4);
   const float inv_count = (float)(1.0 / count);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(ew_grid(total)), dim3(256), 0,
-                                         (hipStream_t)stream, (const E*)dy, (const E*)x, mean, rstd, gamma, beta, C,
-                                         dbeta, dgamma, inv_count, (E*)dx, B, T, Cp));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((Cp + 255) / 256), dim3(256), 0, st, mean, rstd, gamma, beta, C, dbeta,
+                     dgamma, inv_count, coef, Cp);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, st,
+                                         (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
   return check_launch("bn_gelu_backward_apply");
 }
 
@@ -528,7 +549,7 @@ extern "C" int sda_colsum(const void* x, float* out, float* scratch, int B, int 
   const size_t lds = (size_t)RG * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((col_reduce_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)x,
                                          (const E*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, B, T, Cp));
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 31) / 32), dim3(256), 0, st, scratch, nb, out, (float*)nullptr, Cp);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 15) / 16), dim3(256), 0, st, scratch, nb, out, (float*)nullptr, Cp);
   return check_launch("colsum");
 }
 

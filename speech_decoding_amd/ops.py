@@ -123,7 +123,7 @@ def conv_tile_co(Cout_p: int) -> int:
 
 
 def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=None, stats=None, gelu=False,
-              alg_dims=None):
+              alg_dims=None, dbg_flags=0):
     """RL conv: x (rows, Cin_p), w (nW, KS, Cout_p, Cin_p) packed, y (rows, Cout_p).
     alg_dims = (Cin, Cout) unpadded, only used to count algorithmic FLOPs when the timer is on."""
     _need_cuda(x, w, y)
@@ -138,7 +138,7 @@ def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=N
     if x.shape[0] < L.rows_alloc(B, T) or y.shape[0] < L.rows_alloc(B, T):
         raise L.SdaError("conv_gemm: RL buffers too small for (B, T)")
     a.w_rows_limit, a.ksplit = y.shape[1], 1
-    a.flags, a.dtype = (L.EPI_GELU if gelu else 0), dt_code(x.dtype)
+    a.flags, a.dtype = (L.EPI_GELU if gelu else 0) | dbg_flags, dt_code(x.dtype)
     if TIMER is not None:
         cin, cout = alg_dims if alg_dims is not None else (x.shape[1], y.shape[1])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -209,8 +209,9 @@ def bn_gelu_backward(dy, x, mean, rstd, gamma, beta, dx, B, T, scratch, count=No
                                             _p(dgamma), _p(dbeta), B, T, Cp, dt_code(x.dtype), _st()), "bn_gelu_backward_reduce")
     if allreduce is not None:
         allreduce(sums)
+    coef = torch.empty(6 * Cp, dtype=torch.float32, device=x.device)
     L.check(lib.sda_bn_gelu_backward_apply(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), gamma.numel(), _p(dgamma),
-                                           _p(dbeta), float(count if count is not None else B * T), _p(dx), B, T, Cp,
+                                           _p(dbeta), float(count if count is not None else B * T), _p(coef), _p(dx), B, T, Cp,
                                            dt_code(x.dtype), _st()), "bn_gelu_backward_apply")
     return dgamma, dbeta
 

@@ -1,0 +1,46 @@
+"""Micro-benchmark of conv_gemm / wgrad_gemm at config-2 shapes (diagnostic; not part of the product)."""
+import sys, os, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from speech_decoding_amd import ops, lib as L
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3   # us
+
+def main():
+    dev = "cuda:0"
+    B, T = 256, 360
+    for dtype in (torch.bfloat16, torch.float32):
+        for (cin, cout, KS, dil) in [(320, 320, 3, 4), (320, 640, 3, 2), (320, 320, 1, 0), (640, 1024, 1, 0)]:
+            x = ops.new_rows(B, T, cin, dtype, dev); x.normal_()
+            w = torch.randn(cout, cin, KS, device=dev) / math.sqrt(KS * cin)
+            wp = ops.pack_conv_weight(w, cout, cin, dtype)
+            y = ops.new_rows(B, T, cout, dtype, dev)
+            bias = torch.zeros(cout, device=dev)
+            stats = torch.zeros((B * ops.n_t_tiles(T), 2, cout), device=dev)
+            res = x if cin == cout else None
+            fl = 2.0 * B * T * KS * cin * cout
+            for name, kw in [("full", dict(bias=bias, res=res, stats=stats)), ("plain", dict()),
+                             ("no_epi", dict(dbg_flags=256)), ("no_main", dict(bias=bias, res=res, stats=stats, dbg_flags=512)),
+                             ("neither", dict(dbg_flags=768))]:
+                us = timeit(lambda: ops.conv_gemm(x, wp, y, B=B, T=T, KS=KS, dil=dil, **kw))
+                print(f"conv {str(dtype)[6:]:8s} {cin}->{cout} k{KS} {name:8s} {us:8.1f} us  {fl/us/1e6:7.1f} TF", flush=True)
+            if KS == 3 or cout == 1024:
+                dy = ops.new_rows(B, T, cout, dtype, dev); dy.normal_()
+                tile_m = 160 if cout % 160 == 0 else 128
+                ntiles = (cout // tile_m) * (cin // 64)
+                nseg = max(1, min(B, round(256 / ntiles)))
+                import numpy as np
+                seg = torch.from_numpy(np.floor(np.linspace(0, B, nseg + 1)).astype(np.int32)).to(dev)
+                perm = torch.arange(B, dtype=torch.int32, device=dev)
+                us = timeit(lambda: ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=perm, seg_start=seg, nseg=nseg))
+                print(f"wgrad {str(dtype)[6:]:8s} {cin}->{cout} k{KS} nseg={nseg:3d} {us:8.1f} us  {fl/us/1e6:7.1f} TF", flush=True)
+
+if __name__ == "__main__":
+    main()
