@@ -122,6 +122,12 @@ int sda_glu_forward(const void* x, void* y, int B, int T, int Ch, int dtype, voi
 int sda_glu_backward(const void* x, const void* dy, void* dx, int B, int T, int Ch, int dtype, void* stream);
 /* du = dz * GELU'(u) */
 int sda_gelu_backward(const void* u, const void* dz, void* du, int B, int T, int Cp, int dtype, void* stream);
+/* the same two backward stages fused with the column sums of their own output (= the bias gradient of the
+ * layer that produced x / u): colsum fp32 [2*Ch] resp. [Cp]; scratch sda_reduce_scratch_floats(.) floats */
+int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, float* colsum, float* scratch, int B, int T,
+                            int Ch, int dtype, void* stream);
+int sda_gelu_backward_colsum(const void* u, const void* dz, void* du, float* colsum, float* scratch, int B, int T,
+                             int Cp, int dtype, void* stream);
 /* column sums of an RL tensor over valid rows: out[c] = sum_{b,t} x[b,t,c]  (bias gradients) */
 int sda_colsum(const void* x, float* out, float* scratch /* sda_reduce_scratch_floats(Cp) */, int B, int T,
                int Cp, int dtype, void* stream);
@@ -142,7 +148,8 @@ typedef struct sda_wgrad_args {
   int nseg, B, T, Cout_p, Cin_p, KS, dil;
   long dy_pitch, x_pitch, out_pitch;
   long row0, sample_rows; /* as in sda_conv_args */
-  long rows_limit;        /* rows of x at or beyond this index read as zero */
+  long rows_limit;        /* x rows are clamped into [0, rows_limit) (they only meet zero dy rows out there) */
+  long dy_zero_row;       /* index of a row of dy that is all zero (row 0 of any RL buffer); stands in for t >= T */
   int co_valid;           /* rows of out_e to write (out_e mode) */
   int dtype;
 } sda_wgrad_args;

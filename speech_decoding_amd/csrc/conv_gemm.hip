@@ -69,7 +69,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
 
   int bid = blockIdx.x;
   const int n_co = a.Cout_p / TILE_CO;
-  const int co_tile = bid % n_co; bid /= n_co;
+  // XCD-aware order (blocks i and i+8 share an XCD/L2): the n_co tiles that read the same input rows are
+  // dealt to the same XCD.  Pure speed: any placement is correct.
+  int co_tile;
+  {
+    const int group = 8 * n_co, full = (int)(gridDim.x / group) * group;
+    if (bid < full) {
+      const int base = bid / group * group, rem = bid - base;
+      co_tile = rem / 8;
+      bid = (base + (rem & 7) * n_co + co_tile) / n_co;      // = base / n_co + (rem & 7)
+    } else {
+      co_tile = bid % n_co; bid /= n_co;
+    }
+  }
   const int t_tile = bid % n_t_tiles; bid /= n_t_tiles;
   const int b = bid % a.B;
   const int ks = bid / a.B;
@@ -100,9 +112,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
   // operand (only possible in split-K matrix mode) are clamped: they feed outputs that are never stored.
   const int prow = lane >> 2;                                   // row within the piece
   const int pchunk = lane & 3;                                  // physical chunk written by this lane
-  auto stage = [&](int s, int buf) {
+  // x pieces: wave w takes pieces w, w+4, ...; w pieces likewise.  `part`/`nparts` split a slab's DMA
+  // issue into KS interleavable portions so the issue cost hides behind the MFMAs of the current slab.
+  auto stage_x = [&](int s, int buf) {
     unsigned char* xs = smem + buf * STAGE;
-    unsigned char* ws = xs + XS_BYTES;
     const size_t koff = (size_t)s * SLAB;
     for (int p = wid; p < x_pieces; p += 4) {
       const int r = p * 16 + prow;
@@ -112,27 +125,36 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
       __builtin_amdgcn_global_load_lds((gmem_cv*)(xg + (size_t)row * a.x_pitch + koff + lc * PER16),
                                        (lds_v*)(xs + p * 1024), 16, 0, 0);
     }
+  };
+  auto stage_w = [&](int s, int buf, int tap) {          // the TILE_CO rows of one tap
+    unsigned char* ws = smem + buf * STAGE + XS_BYTES;
+    const size_t koff = (size_t)s * SLAB;
+    constexpr int TP = TILE_CO / 16;                      // pieces per tap
 #pragma unroll
-    for (int i = 0; i < (W_PIECES + 3) / 4; ++i) {
-      const int p = wid + i * 4;
-      if (p < W_PIECES) {
-        const int r = p * 16 + prow;                            // row of the [tap][co] weight image
-        const int tap = r / TILE_CO;
-        int co = co0 + (r - tap * TILE_CO);
+    for (int i = 0; i < (TP + 3) / 4; ++i) {
+      const int q = wid + i * 4;
+      if (q < TP) {
+        const int r = tap * TILE_CO + q * 16 + prow;      // row of the [tap][co] weight image
+        int co = co0 + q * 16 + prow;
         co = co < a.w_rows_limit ? co : a.w_rows_limit - 1;
         const int lc = (pchunk ^ (r >> 2)) & 3;
         __builtin_amdgcn_global_load_lds((gmem_cv*)(wg + ((size_t)tap * a.Cout_p + co) * a.w_pitch + koff + lc * PER16),
-                                         (lds_v*)(ws + p * 1024), 16, 0, 0);
+                                         (lds_v*)(ws + (tap * TP + q) * 1024), 16, 0, 0);
       }
     }
   };
 
-  if (s_begin < s_end) stage(s_begin, 0);
+  if (s_begin < s_end) {
+    stage_x(s_begin, 0);
+#pragma unroll
+    for (int tap = 0; tap < KS; ++tap) stage_w(s_begin, 0, tap);
+  }
   for (int s = s_begin; s < s_end; ++s) {
     const int cur = (s - s_begin) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of slab s have landed
     __syncthreads();                                    // ... everybody's have, and slab s-1 is fully consumed
-    if (s + 1 < s_end) stage(s + 1, cur ^ 1);           // DMA of the next slab overlaps the MFMAs below
+    const bool more = s + 1 < s_end;
+    if (more) stage_x(s + 1, cur ^ 1);                  // DMA of the next slab overlaps the MFMAs below
     const unsigned char* xs = smem + cur * STAGE;
     const unsigned char* ws = xs + XS_BYTES;
 #pragma unroll
@@ -144,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
       for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow + m * 16, lq));
 #pragma unroll
       for (int n = 0; n < NREP; ++n) bf[n] = *reinterpret_cast<const uint4*>(ws + lds_sw64(wrow + n * 16, lq));
+      if (more) stage_w(s + 1, cur ^ 1, tap);           // issue this tap's share of the next slab between MFMA groups
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll

@@ -277,6 +277,69 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
   }
 }
 
+// Backward elementwise stage fused with the column sums of its own output (bias gradients of the layer
+// below), same thread->channel ownership as col_reduce_kernel.
+//   MODE 0 (GELU):  du = dz * GELU'(u);  partial[blk][0][c] = sum du
+//   MODE 1 (GLU):   x = [a | g] (2*Ch channels), dy (Ch): da = dy*sig(g), dg = dy*a*sig(g)*(1-sig(g));
+//                   partial[blk][0][c] = sum da, partial[blk][1][c] = sum dg      (c < Ch)
+template <typename E, int MODE>
+__global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x, const E* __restrict__ dy,
+                                                         E* __restrict__ dx, float* __restrict__ partial, int B, int T,
+                                                         int Ch) {
+  extern __shared__ float red[];
+  const int nch = Ch / 4;
+  const int RG = 256 / nch;
+  const int ch = threadIdx.x % nch, rg = threadIdx.x / nch;
+  const size_t rows = (size_t)B * T;
+  const size_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const size_t r0 = (size_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+  const int xw = MODE == 1 ? 2 * Ch : Ch;
+  float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  if (rg < RG) {
+    for (size_t r = r0 + rg; r < r1; r += RG) {
+      const int b = r / T, t = r - (size_t)b * T;
+      const size_t row = (size_t)b * rows_tp(T) + PAD + t;
+      const float4 d4 = load4(dy + row * Ch + ch * 4);
+      const float4 x4 = load4(x + row * xw + ch * 4);
+      const float d[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+      float o0[4], o1[4];
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o0[j] = d[j] * gelu_grad_f(xv[j]); a0[j] += o0[j]; }
+        store4(dx + row * Ch + ch * 4, make_float4(o0[0], o0[1], o0[2], o0[3]));
+      } else {
+        const float4 g4 = load4(x + row * xw + Ch + ch * 4);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sg = sigmoid_f(g[j]);
+          o0[j] = d[j] * sg;
+          o1[j] = d[j] * xv[j] * sg * (1.f - sg);
+        }
+        const float4 q0 = make_float4(o0[0], o0[1], o0[2], o0[3]), q1 = make_float4(o1[0], o1[1], o1[2], o1[3]);
+        store4(dx + row * xw + ch * 4, q0);
+        store4(dx + row * xw + Ch + ch * 4, q1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[j] += o0[j]; a1[j] += o1[j]; }
+      }
+    }
+  }
+  if (rg < RG) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[(rg * 2 + 0) * Ch + ch * 4 + j] = a0[j];
+      red[(rg * 2 + 1) * Ch + ch * 4 + j] = a1[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * Ch; i += 256) {
+    const int which = i / Ch, c = i - which * Ch;
+    float sum = 0.f;
+    for (int g = 0; g < RG; ++g) sum += red[(g * 2 + which) * Ch + c];
+    partial[((size_t)blockIdx.x * 2 + which) * Ch + c] = sum;
+  }
+}
+
 // sums[which][c] = sum over blocks (fp64, fixed order)
 __global__ __launch_bounds__(256) void col_reduce_final_kernel(const float* __restrict__ partial, int nblocks,
                                                                float* __restrict__ out0, float* __restrict__ out1, int Cp) {
@@ -577,6 +640,30 @@ extern "C" int sda_gelu_backward(const void* u, const void* dz, void* du, int B,
   SDA_DISPATCH(dtype, hipLaunchKernelGGL(gelu_bwd_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                                          (const E*)u, (const E*)dz, (E*)du, B, T, Cp));
   return check_launch("gelu_backward");
+}
+
+extern "C" int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, float* colsum, float* scratch, int B, int T,
+                                       int Ch, int dtype, void* stream) {
+  if (!x || !dy || !dx || !colsum || !scratch || Ch % 64 || Ch > 1024) { set_error("glu_backward_colsum: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = red_blocks(B, T);
+  const size_t lds = (size_t)(256 / (Ch / 4)) * 2 * Ch * sizeof(float);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)x,
+                                         (const E*)dy, (E*)dx, scratch, B, T, Ch));
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 15) / 16), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
+  return check_launch("glu_backward_colsum");
+}
+
+extern "C" int sda_gelu_backward_colsum(const void* u, const void* dz, void* du, float* colsum, float* scratch, int B, int T,
+                                        int Cp, int dtype, void* stream) {
+  if (!u || !dz || !du || !colsum || !scratch || Cp % 64 || Cp > 1024) { set_error("gelu_backward_colsum: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = red_blocks(B, T);
+  const size_t lds = (size_t)(256 / (Cp / 4)) * 2 * Cp * sizeof(float);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)u,
+                                         (const E*)dz, (E*)du, scratch, B, T, Cp));
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 15) / 16), dim3(256), 0, st, scratch, nb, colsum, (float*)nullptr, Cp);
+  return check_launch("gelu_backward_colsum");
 }
 
 extern "C" int sda_reduce_slabs(const float* src, float* dst, int nslabs, long n, void* stream) {

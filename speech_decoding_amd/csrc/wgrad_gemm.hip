@@ -16,20 +16,43 @@
 
 namespace sda {
 
-constexpr int WG_KT = 64;       // rows (time steps) per staged chunk
 constexpr int WG_TN = 64;       // ci columns per workgroup
 
-template <typename E> struct WImg;      // row stride (bytes) of an LDS image holding `cols` elements per row
-template <> struct WImg<uint16_t> { static __host__ __device__ constexpr int stride(int cols) { return cols * 2 + 32; } };
-template <> struct WImg<float> { static __host__ __device__ constexpr int stride(int cols) { return cols * 4 + 64; } };
+// Rows staged per K-chunk = two MFMA K-steps: 64 rows (bf16, 32 per step) / 32 rows (fp32, 16 per step).
+template <typename E> struct WK;
+template <> struct WK<uint16_t> { static constexpr int KSTEP = 32, KT = 64; };
+template <> struct WK<float> { static constexpr int KSTEP = 16, KT = 32; };
 
-// transposed MFMA operand: 16 columns starting at col0, 32 (bf16) / 16 (fp32) rows starting at row0
-__device__ inline uint4 tr_operand_bf16(const unsigned char* img, int stride, int row0, int col0, int lane) {
+typedef __attribute__((address_space(1))) const void gmem_cv;
+typedef __attribute__((address_space(3))) void lds_v;
+
+// LDS images are plain row-major copies (row = time step, RB bytes per row, no padding) filled by 1 KB
+// LDS-DMA pieces; bank conflicts of the TRANSPOSED operand reads are removed by XOR-ing the 16-byte chunk
+// index with a function of the row (applied to the DMA source address and to the read address alike):
+//   bf16 (ds_read_b64_tr_b16, a 32-lane half reads 8 consecutive rows x 32 B):  32-byte groups
+//       RB = 128: group ^= (row >> 1) & 3     RB = 256: group ^= row & 7     RB = 320: group ^= (row >> 2) & 1
+//   fp32 (ds_read_b32, a half reads 2 consecutive rows x 64 B):  64-byte groups, group ^= row & 1
+template <typename E, int RB> __device__ inline int chunk_xor(int row) {
+  if (sizeof(E) == 4) return (row & 1) << 2;
+  if (RB == 128) return ((row >> 1) & 3) << 1;
+  if (RB == 256) return (row & 7) << 1;
+  if (RB == 320) return ((row >> 2) & 1) << 1;
+  return 0;
+}
+
+// transposed MFMA operand: 16 columns starting at col0; rows row0.. (32 for bf16, 16 for fp32).
+// Lane group g supplies k = {4g..4g+3, 16+4g..16+4g+3} (bf16) / {g, 4+g, 8+g, 12+g} (fp32) for BOTH operands.
+template <typename E, int RB> __device__ inline uint4 tr_operand(const unsigned char* img, int row0, int col0, int lane);
+
+template <int RB> __device__ inline uint4 tr_operand_bf16(const unsigned char* img, int row0, int col0, int lane) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const unsigned char* a0 = img + (row0 + 4 * g + q) * stride + (col0 + 4 * p) * 2;
+  const int row = row0 + 4 * g + q;
+  const int colb = (col0 + 4 * p) * 2;                         // byte column, multiple of 8
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const unsigned char* a0 = img + row * RB + ((((colb >> 4) ^ chunk_xor<uint16_t, RB>(row))) << 4) + (colb & 15);
+  const unsigned char* a1 = img + (row + 16) * RB + ((((colb >> 4) ^ chunk_xor<uint16_t, RB>(row + 16))) << 4) + (colb & 15);
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * stride));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1));
   uint4 r;
   r.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
   r.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
@@ -37,37 +60,50 @@ __device__ inline uint4 tr_operand_bf16(const unsigned char* img, int stride, in
   r.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
   return r;
 }
-// fp32: element j of the lane = row (row0 + 4*j + g)... any bijection works as long as A and B agree
-__device__ inline uint4 tr_operand_f32(const unsigned char* img, int stride, int row0, int col0, int lane) {
+template <int RB> __device__ inline uint4 tr_operand_f32(const unsigned char* img, int row0, int col0, int lane) {
   const int g = lane >> 4, i = lane & 15;
-  const unsigned char* a0 = img + (row0 + g) * stride + (col0 + i) * 4;
+  const int colb = (col0 + i) * 4;
   uint4 r;
-  r.x = *reinterpret_cast<const uint32_t*>(a0);
-  r.y = *reinterpret_cast<const uint32_t*>(a0 + 4 * stride);
-  r.z = *reinterpret_cast<const uint32_t*>(a0 + 8 * stride);
-  r.w = *reinterpret_cast<const uint32_t*>(a0 + 12 * stride);
+  uint32_t* rp = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = row0 + g + 4 * j;
+    rp[j] = *reinterpret_cast<const uint32_t*>(img + row * RB + (((colb >> 4) ^ chunk_xor<float, RB>(row)) << 4) + (colb & 15));
+  }
   return r;
 }
-template <typename E> __device__ inline uint4 tr_operand(const unsigned char* img, int stride, int row0, int col0, int lane);
-template <> __device__ inline uint4 tr_operand<uint16_t>(const unsigned char* img, int stride, int row0, int col0, int lane) {
-  return tr_operand_bf16(img, stride, row0, col0, lane);
-}
-template <> __device__ inline uint4 tr_operand<float>(const unsigned char* img, int stride, int row0, int col0, int lane) {
-  return tr_operand_f32(img, stride, row0, col0, lane);
-}
+template <typename E, int RB> struct TrOp;
+template <int RB> struct TrOp<uint16_t, RB> {
+  __device__ static uint4 get(const unsigned char* img, int row0, int col0, int lane) { return tr_operand_bf16<RB>(img, row0, col0, lane); }
+};
+template <int RB> struct TrOp<float, RB> {
+  __device__ static uint4 get(const unsigned char* img, int row0, int col0, int lane) { return tr_operand_f32<RB>(img, row0, col0, lane); }
+};
+
+template <typename E, int TILE_M, int KS> struct WGeom {
+  static constexpr int KT = WK<E>::KT;
+  static constexpr int RB_M = TILE_M * (int)sizeof(E);          // dy image row bytes
+  static constexpr int RB_N = WG_TN * (int)sizeof(E);           // x image row bytes
+  static constexpr int DY_BYTES = KT * RB_M;
+  static constexpr int XR = KT + 2 * PAD;
+  static constexpr int X_BYTES = XR * RB_N;
+  static constexpr int STAGE = DY_BYTES + X_BYTES;
+  static constexpr int DY_PIECES = DY_BYTES / 1024;
+  static constexpr int EPI_BYTES = TILE_M * (WG_TN + 4) * 4;
+  static constexpr int LDS = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  static_assert(DY_BYTES % 1024 == 0 && X_BYTES % 1024 == 0, "images must be whole 1 KB pieces");
+};
 
 template <typename E, int TILE_M, int KS>
 __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = WGeom<E, TILE_M, KS>;
   constexpr int PER16 = Elem<E>::PER16;
-  constexpr int KSTEP = (sizeof(E) == 2) ? 32 : 16;        // rows consumed per mma16
+  constexpr int KSTEP = WK<E>::KSTEP, KT = WK<E>::KT;
   constexpr int MREP = TILE_M / 32;                         // 16-row m tiles per wave (wave tile = TILE_M/2 x 32)
-  constexpr int DY_STRIDE = WImg<E>::stride(TILE_M);
-  constexpr int X_STRIDE = WImg<E>::stride(WG_TN);
-  constexpr int DY_BYTES = WG_KT * DY_STRIDE;
-  constexpr int M_CHUNKS = TILE_M / PER16, N_CHUNKS = WG_TN / PER16;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wid >> 1, wave_n = wid & 1;
   const int lr = lane & 15, lq = lane >> 4;
 
@@ -78,10 +114,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
   const int seg = bid;
   const int co0 = m_tile * TILE_M, ci0 = n_tile * WG_TN;
   const int halo = (KS == 3) ? a.dil : 0;
-  const int XR = WG_KT + 2 * halo;
-
-  unsigned char* dys = smem;
-  unsigned char* xs = smem + DY_BYTES;
+  const int x_pieces = ((KT + 2 * halo) * G::RB_N + 1023) >> 10;
 
   f32x4 acc[KS][MREP][2];
 #pragma unroll
@@ -93,45 +126,66 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
   const E* __restrict__ xg = reinterpret_cast<const E*>(a.x);
   const int s_beg = a.seg_start ? a.seg_start[seg] : 0;
   const int s_end = a.seg_start ? a.seg_start[seg + 1] : a.B;
+  const int nchunk = (a.T + KT - 1) / KT;
+  const int total = (s_end - s_beg) * nchunk;
 
-  for (int si = s_beg; si < s_end; ++si) {
-    const int b = a.perm ? a.perm[si] : si;
+  // one K-chunk = KT rows of one sample.  DMA pieces are 1 KB, lane-linear in LDS; each lane derives the
+  // (row, chunk) its 16 bytes belong to and fetches the swizzle-matched source chunk.  dy rows at t >= T
+  // come from a guaranteed-zero row (they must not contribute); x rows are merely clamped into the buffer.
+  auto stage = [&](int it, int buf) {
+    const int si = it / nchunk, ch = it - si * nchunk;
+    const int b = a.perm ? a.perm[s_beg + si] : (s_beg + si);
     const long srow = a.row0 + (long)b * a.sample_rows;
-    for (int t0 = 0; t0 < a.T; t0 += WG_KT) {
-      __syncthreads();
-      for (int idx = tid; idx < WG_KT * M_CHUNKS; idx += 256) {
-        const int r = idx / M_CHUNKS, c = idx - r * M_CHUNKS;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (t0 + r < a.T)
-          v = *reinterpret_cast<const uint4*>(dyg + (size_t)(srow + t0 + r) * a.dy_pitch + co0 + c * PER16);
-        *reinterpret_cast<uint4*>(dys + r * DY_STRIDE + c * 16) = v;
-      }
-      for (int idx = tid; idx < XR * N_CHUNKS; idx += 256) {
-        const int r = idx / N_CHUNKS, c = idx - r * N_CHUNKS;
-        const long row = srow + t0 - halo + r;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row >= 0 && row < a.rows_limit)
-          v = *reinterpret_cast<const uint4*>(xg + (size_t)row * a.x_pitch + ci0 + c * PER16);
-        *reinterpret_cast<uint4*>(xs + r * X_STRIDE + c * 16) = v;
-      }
-      __syncthreads();
+    const int t0 = ch * KT;
+    unsigned char* dys = smem + buf * G::STAGE;
+    unsigned char* xs = dys + G::DY_BYTES;
 #pragma unroll
-      for (int kk = 0; kk < WG_KT / KSTEP; ++kk) {
-        uint4 af[MREP];
+    for (int i = 0; i < (G::DY_PIECES + 3) / 4; ++i) {
+      const int p = wid + i * 4;
+      if (p < G::DY_PIECES) {
+        const int byte = p * 1024 + lane * 16;
+        const int r = byte / G::RB_M;
+        const int c = ((byte - r * G::RB_M) >> 4) ^ chunk_xor<E, G::RB_M>(r);
+        const long row = (t0 + r < a.T) ? (srow + t0 + r) : a.dy_zero_row;
+        __builtin_amdgcn_global_load_lds((gmem_cv*)(dyg + (size_t)row * a.dy_pitch + co0 + c * PER16),
+                                         (lds_v*)(dys + p * 1024), 16, 0, 0);
+      }
+    }
+    for (int p = wid; p < x_pieces; p += 4) {
+      const int byte = p * 1024 + lane * 16;
+      const int r = byte / G::RB_N;
+      const int c = ((byte - r * G::RB_N) >> 4) ^ chunk_xor<E, G::RB_N>(r);
+      long row = srow + t0 - halo + r;
+      row = row < 0 ? 0 : (row >= a.rows_limit ? a.rows_limit - 1 : row);
+      __builtin_amdgcn_global_load_lds((gmem_cv*)(xg + (size_t)row * a.x_pitch + ci0 + c * PER16),
+                                       (lds_v*)(xs + p * 1024), 16, 0, 0);
+    }
+  };
+
+  if (total > 0) stage(0, 0);
+  for (int it = 0; it < total; ++it) {
+    const int cur = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 1 < total) stage(it + 1, cur ^ 1);
+    const unsigned char* dys = smem + cur * G::STAGE;
+    const unsigned char* xs = dys + G::DY_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < KT / KSTEP; ++kk) {
+      uint4 af[MREP];
+#pragma unroll
+      for (int m = 0; m < MREP; ++m)
+        af[m] = TrOp<E, G::RB_M>::get(dys, kk * KSTEP, wave_m * (TILE_M / 2) + m * 16, lane);
+#pragma unroll
+      for (int tap = 0; tap < KS; ++tap) {
+        uint4 bf[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          bf[n] = TrOp<E, G::RB_N>::get(xs, kk * KSTEP + tap * a.dil, wave_n * 32 + n * 16, lane);
 #pragma unroll
         for (int m = 0; m < MREP; ++m)
-          af[m] = tr_operand<E>(dys, DY_STRIDE, kk * KSTEP, wave_m * (TILE_M / 2) + m * 16, lane);
 #pragma unroll
-        for (int tap = 0; tap < KS; ++tap) {
-          uint4 bf[2];
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-            bf[n] = tr_operand<E>(xs, X_STRIDE, kk * KSTEP + tap * a.dil, wave_n * 32 + n * 16, lane);
-#pragma unroll
-          for (int m = 0; m < MREP; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) acc[tap][m][n] = mma16<E>(af[m], bf[n], acc[tap][m][n]);
-        }
+          for (int n = 0; n < 2; ++n) acc[tap][m][n] = mma16<E>(af[m], bf[n], acc[tap][m][n]);
       }
     }
   }
@@ -182,15 +236,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
   }
 }
 
-template <int TILE_M, int KS, typename E> constexpr int wgrad_lds_bytes() {
-  constexpr int main_b = WG_KT * WImg<E>::stride(TILE_M) + (WG_KT + 2 * PAD) * WImg<E>::stride(WG_TN);
-  constexpr int epi_b = TILE_M * (WG_TN + 4) * 4;
-  return main_b > epi_b ? main_b : epi_b;
-}
-
 template <typename E, int TILE_M, int KS>
 static int launch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
-  constexpr int lds = wgrad_lds_bytes<TILE_M, KS, E>();
+  constexpr int lds = WGeom<E, TILE_M, KS>::LDS;
   static bool attr_done = false;
   auto kern = wgrad_gemm_kernel<E, TILE_M, KS>;
   if (!attr_done) {
@@ -226,6 +274,7 @@ extern "C" int sda_wgrad_gemm(const sda_wgrad_args* a, void* stream) {
   if (a->dy_pitch % 8 || a->x_pitch % 8) { set_error("wgrad_gemm: pitches must be multiples of 8 elements"); return -1; }
   if (a->nseg < 1 || a->B < 1 || a->T < 1) { set_error("wgrad_gemm: empty problem"); return -1; }
   if (a->out_e && (a->KS != 1 || a->nseg != 1 || a->out_pitch % 8)) { set_error("wgrad_gemm: typed output needs KS == 1, nseg == 1"); return -1; }
+  if (a->dy_zero_row < 0) { set_error("wgrad_gemm: dy_zero_row missing"); return -1; }
   if (a->out_e && a->sub && !a->rscale) { set_error("wgrad_gemm: sub needs rscale"); return -1; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == SDA_F32) return dispatch_wgrad<float>(*a, st);

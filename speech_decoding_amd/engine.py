@@ -246,13 +246,15 @@ class EncoderEngine:
                                  alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]))
 
         # ---- final projections
-        du2 = ops.gelu_backward(bufs["u2"], dZt, tmp("du2", d.Fp), B, T)
+        du2 = tmp("du2", d.Fp)
+        cs = ops.gelu_backward_colsum(bufs["u2"], dZt, du2, B, T, scratch)
         grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
-        grads["f2b"] = ops.unpack_vector(ops.colsum(du2, B, T, scratch), d.F)
+        grads["f2b"] = ops.unpack_vector(cs, d.F)
         dg1 = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
-        du1 = ops.gelu_backward(bufs["u1"], dg1, tmp("du1", d.F1p), B, T)
+        du1 = tmp("du1", d.F1p)
+        cs = ops.gelu_backward_colsum(bufs["u1"], dg1, du1, B, T, scratch)
         grads["f1w"] = wgrad(du1, bufs["x5"], 1, 0, d.F1, d.D2)
-        grads["f1b"] = ops.unpack_vector(ops.colsum(du1, B, T, scratch), d.F1)
+        grads["f1b"] = ops.unpack_vector(cs, d.F1)
         dx = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
 
         # ---- ConvBlocks, last to first
@@ -261,9 +263,10 @@ class EncoderEngine:
             cin, cin_p = (d.D1, d.D1p) if k == 0 else (d.D2, d.D2p)
             dil = block_dilations(k)
             glu = dict(glu_half=d.D2, glu_half_p=d.D2p)
-            dc2 = ops.glu_backward(bufs[f"b{k}.c2"], dx, tmp("dc2", 2 * d.D2p), B, T)
+            dc2 = tmp("dc2", 2 * d.D2p)
+            cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
             grads[f"b{k}.c2w"] = wgrad(dc2, bufs[f"b{k}.a1"], 3, dil[2], 2 * d.D2, d.D2, **glu)
-            grads[f"b{k}.c2b"] = ops.unpack_vector(ops.colsum(dc2, B, T, scratch), 2 * d.D2, **glu)
+            grads[f"b{k}.c2b"] = ops.unpack_vector(cs, 2 * d.D2, **glu)
             da1 = dgrad(dc2, None, P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2], **glu)
             x_in = bufs[f"x{k}"]
             for j in (1, 0):

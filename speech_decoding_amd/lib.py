@@ -32,7 +32,7 @@ class WgradArgs(C.Structure):
                 ("seg_start", vp),
                 ("nseg", i32), ("B", i32), ("T", i32), ("Cout_p", i32), ("Cin_p", i32), ("KS", i32), ("dil", i32),
                 ("dy_pitch", i64), ("x_pitch", i64), ("out_pitch", i64), ("row0", i64), ("sample_rows", i64),
-                ("rows_limit", i64), ("co_valid", i32), ("dtype", i32)]
+                ("rows_limit", i64), ("dy_zero_row", i64), ("co_valid", i32), ("dtype", i32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/sd_amd.h
@@ -59,6 +59,8 @@ SIGNATURES = {
     "sda_glu_forward": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sda_glu_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_gelu_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_glu_backward_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_gelu_backward_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_colsum": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_wgrad_gemm": (i32, [C.POINTER(WgradArgs), vp]),
     "sda_reduce_slabs": (i32, [vp, vp, i32, i64, vp]),

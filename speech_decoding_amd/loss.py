@@ -105,7 +105,7 @@ class _ClipFn(torch.autograd.Function):
         dZ = None
         scale = dloss.to(torch.float32)
         if ctx.z_requires_grad:
-            G = (c.G.float() * scale).to(c.G.dtype)          # fold the incoming scalar gradient (B x B, tiny)
+            G = (c.G.float() * scale).to(c.G.dtype)          # keeps the trailing zero row zero          # fold the incoming scalar gradient (B x B, tiny)
             rscale = c.rscale * scale
             c2 = E.ClipCtx(c.Bm, c.Bn, c.col0, G, rscale, c.Yt, c.Zt, c.row_elems, c.dtemp)
             dZt = ops.new_rows(B, T, c.Zt.shape[1], ctx.dtype, c.Zt.device)

@@ -231,6 +231,21 @@ def gelu_backward(u, dz, du, B, T):
     return du
 
 
+def glu_backward_colsum(x, dy, dx, B, T, scratch):
+    """dx = GLU backward; returns the fp32 column sums of dx (2*Ch) = bias gradient of the conv that made x."""
+    cs = torch.empty(2 * dy.shape[1], dtype=torch.float32, device=x.device)
+    L.check(L.load().sda_glu_backward_colsum(_p(x), _p(dy), _p(dx), _p(cs), _p(scratch), B, T, dy.shape[1], dt_code(x.dtype), _st()),
+            "glu_backward_colsum")
+    return cs
+
+
+def gelu_backward_colsum(u, dz, du, B, T, scratch):
+    cs = torch.empty(u.shape[1], dtype=torch.float32, device=u.device)
+    L.check(L.load().sda_gelu_backward_colsum(_p(u), _p(dz), _p(du), _p(cs), _p(scratch), B, T, u.shape[1], dt_code(u.dtype), _st()),
+            "gelu_backward_colsum")
+    return cs
+
+
 def colsum(x, B, T, scratch):
     out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
     L.check(L.load().sda_colsum(_p(x), _p(out), _p(scratch), B, T, x.shape[1], dt_code(x.dtype), _st()), "colsum")
@@ -245,7 +260,7 @@ def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1):
     a.perm, a.seg_start = _p(perm), _p(seg_start)
     a.nseg, a.B, a.T, a.Cout_p, a.Cin_p, a.KS, a.dil = nseg, B, T, dy.shape[1], x.shape[1], KS, dil
     a.dy_pitch, a.x_pitch, a.out_pitch = dy.shape[1], x.shape[1], 0
-    a.row0, a.sample_rows, a.rows_limit = L.ROW_PAD, L.rows_tp(T), x.shape[0]
+    a.row0, a.sample_rows, a.rows_limit, a.dy_zero_row = L.ROW_PAD, L.rows_tp(T), x.shape[0], 0
     a.co_valid, a.dtype = 0, dt_code(x.dtype)
     if nseg > 1 and seg_start is None:
         raise L.SdaError("wgrad_gemm: nseg > 1 needs seg_start")
@@ -269,7 +284,9 @@ def matmul_tn_typed(G, Ym, out, sub, rscale, *, M_rows, N_valid, K_cols, pitch):
     a.perm, a.seg_start = None, None
     a.nseg, a.B, a.T, a.Cout_p, a.Cin_p, a.KS, a.dil = 1, 1, M_rows, G.shape[1], K_cols, 1, 0
     a.dy_pitch, a.x_pitch, a.out_pitch = G.shape[1], pitch, pitch
-    a.row0, a.sample_rows, a.rows_limit = 0, 0, M_rows
+    if G.shape[0] < M_rows + 1:
+        raise L.SdaError("matmul_tn_typed: G needs one trailing all-zero row")
+    a.row0, a.sample_rows, a.rows_limit, a.dy_zero_row = 0, 0, M_rows, M_rows
     a.co_valid, a.dtype = N_valid, dt_code(Ym.dtype)
     L.check(L.load().sda_wgrad_gemm(C.byref(a), _st()), "wgrad_gemm(typed)")
     return out
@@ -309,7 +326,7 @@ def clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0):
 def clip_grad(logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, dtype):
     Bm, Bn = logits.shape
     dev = logits.device
-    G = torch.zeros((Bm, L.pad_channels(Bn)), dtype=dtype, device=dev)
+    G = torch.zeros((Bm + 1, L.pad_channels(Bn)), dtype=dtype, device=dev)      # + one zero row (wgrad_gemm's t >= T stand-in)
     rscale = torch.empty(Bn, dtype=torch.float32, device=dev)
     colpart = torch.empty(2 * Bn, dtype=torch.float32, device=dev)
     scalars = torch.empty(2, dtype=torch.float32, device=dev)

@@ -259,6 +259,17 @@ def test_glu_gelu_colsum(ops, dtype):
     np.testing.assert_allclose(from_rows(ops, du, B, Ch, T).numpy(), u.grad.numpy(), **tol(dtype))
     cs = ops.colsum(to_rows(ops, dy, dtype), B, T, ops.reduce_scratch(Chp, DEV))
     np.testing.assert_allclose(cs[:Ch].cpu().numpy(), dy.sum(dim=(0, 2)).numpy(), rtol=1e-4, atol=1e-3)
+    # fused variants: same outputs + column sums of the outputs (bias gradients)
+    dxb2 = ops.new_rows(B, T, 2 * Chp, dtype, DEV)
+    cs2 = ops.glu_backward_colsum(xb, to_rows(ops, dy, dtype), dxb2, B, T, ops.reduce_scratch(2 * Chp, DEV))
+    assert torch.equal(dxb2, dxb)
+    dx_stored = from_rows(ops, dxb2, B, 2 * Chp, T)
+    t = tol(dtype, B * T)
+    np.testing.assert_allclose(cs2.cpu().numpy(), dx_stored.sum(dim=(0, 2)).numpy(), rtol=t["rtol"], atol=t["atol"])
+    du2 = ops.new_rows(B, T, Chp, dtype, DEV)
+    cs3 = ops.gelu_backward_colsum(to_rows(ops, u.detach(), dtype), to_rows(ops, dy, dtype), du2, B, T, ops.reduce_scratch(Chp, DEV))
+    assert torch.equal(du2, du)
+    np.testing.assert_allclose(cs3[:Ch].cpu().numpy(), u.grad.sum(dim=(0, 2)).numpy(), rtol=t["rtol"], atol=t["atol"])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
