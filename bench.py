@@ -77,11 +77,17 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
+    # rehearsal-only overrides (several ranks on a one-GPU box): SDA_FORCE_DEVICE=0 SDA_DIST_BACKEND=gloo
+    local = int(os.environ.get("SDA_FORCE_DEVICE", local))
+    backend = os.environ.get("SDA_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from oracle import brain_oracle as O           # data generator + cpu_baseline leg only
     from speech_decoding_amd import Classifier, BrainEncoder, CLIPLoss, load_config, ops

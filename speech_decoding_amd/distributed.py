@@ -69,7 +69,7 @@ def merge_row_softmax_stats(row_max: torch.Tensor, row_sum: torch.Tensor, group=
     """Each rank holds, for every GLOBAL speech row, (max, sum exp(l - max)) over ITS OWN block of brain
     columns.  Returns the row-wise log-sum-exp over all columns of all ranks (2 small all-reduces):
         M = max_r m_r ;  S = sum_r s_r * exp(m_r - M) ;  lse = M + log S."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if group is not None and dist.is_initialized() and dist.get_world_size(group) > 1:     # None = stay local
         gmax = row_max.clone()
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
         row_sum = row_sum * torch.exp(row_max - gmax)

@@ -69,6 +69,19 @@ def _dist_group():
     return None
 
 
+def gather_speech_rows(Yt_local: torch.Tensor, B: int, T: int, group):
+    """All-gather the packed speech rows of every rank (RCCL all_gather over xGMI; samples are contiguous
+    blocks of Tp rows, so the gather lands directly in RL order).  Returns (Yt, Bm, col0, B_global)."""
+    if group is None:
+        return Yt_local, B, 0, B
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    Tp = L.rows_tp(T)
+    Yt = ops.new_rows(B * world, T, Yt_local.shape[1], Yt_local.dtype, Yt_local.device)
+    dist.all_gather_into_tensor(Yt[: B * world * Tp], Yt_local[: B * Tp].contiguous(), group=group)
+    return Yt, B * world, rank * B, B * world
+
+
 class _ClipFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: "CLIPLoss", Y, Z, temp):
@@ -78,15 +91,7 @@ class _ClipFn(torch.autograd.Function):
         Zt = as_rows(Z, B, F, T, dtype, "y (brain embeddings)")
         Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)")
         group = _dist_group() if module.global_negatives else None
-        if group is not None:
-            world, rank = dist.get_world_size(group), dist.get_rank(group)
-            Tp, Fp = L.rows_tp(T), Zt.shape[1]
-            Yt = ops.new_rows(B * world, T, Fp, dtype, Zt.device)
-            # samples are contiguous blocks of Tp rows, so the gather lands directly in RL order
-            dist.all_gather_into_tensor(Yt[: B * world * Tp], Yt_local[: B * Tp].contiguous(), group=group)
-            Bm, col0, Bg = B * world, rank * B, B * world
-        else:
-            Yt, Bm, col0, Bg = Yt_local, B, 0, B
+        Yt, Bm, col0, Bg = gather_speech_rows(Yt_local, B, T, group)
         loss, logits, cnt, cctx = E.clip_forward(Yt, Zt, temp.detach(), Bm=Bm, Bn=B, T=T, col0=col0,
                                                  reduction=module.reduction, B_global=Bg, dist_group=group)
         if group is not None:
@@ -140,7 +145,7 @@ class CLIPLoss(nn.Module):
 
 
 @torch.no_grad()
-def retrieval_ranks(Y: torch.Tensor, Z: torch.Tensor) -> torch.Tensor:
+def retrieval_ranks(Y: torch.Tensor, Z: torch.Tensor, global_candidates: bool = True) -> torch.Tensor:
     """Rank of each speech row's own brain column (0 = top-1).  Reuses the ranks computed by the last
     CLIPLoss forward on the same tensors; otherwise runs the similarity GEMM + rank kernel."""
     hit = _cached_ranks(Y, Z)
@@ -151,5 +156,10 @@ def retrieval_ranks(Y: torch.Tensor, Z: torch.Tensor) -> torch.Tensor:
     Zt = as_rows(Z, B, F, T, dtype, "Z")
     Yt = as_rows(Y, B, F, T, dtype, "Y")
     temp = torch.zeros(1, dtype=torch.float32, device=Zt.device)
-    _, _, cnt, _ = E.clip_forward(Yt, Zt, temp, Bm=B, Bn=B, T=T)
-    return cnt
+    group = _dist_group() if global_candidates else None     # under data parallelism: the GLOBAL batch
+    Yt, Bm, col0, Bg = gather_speech_rows(Yt, B, T, group)
+    _, _, cnt, _ = E.clip_forward(Yt, Zt, temp, Bm=Bm, Bn=B, T=T, col0=col0, B_global=Bg, dist_group=group)
+    if group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(cnt, group=group)
+    return cnt[col0: col0 + B]

@@ -264,12 +264,13 @@ class Classifier(nn.Module):
     def __init__(self, args=None):
         super().__init__()
         self.factor = 1
+        self.global_candidates = True       # under torch.distributed: rank against the global batch
 
     @torch.no_grad()
     def forward(self, Z: torch.Tensor, Y: torch.Tensor, test: bool = False):
         B = Z.size(0)
         if B < 10:
             raise RuntimeError("selected index k out of range")      # torch.topk(…, 10) on fewer than 10 columns
-        cnt = _loss.retrieval_ranks(Y, Z)
+        cnt = _loss.retrieval_ranks(Y, Z, self.global_candidates)
         cnt = cnt.cpu().numpy()
         return float((cnt == 0).mean()), np.mean(cnt < 10)

@@ -71,7 +71,7 @@ def _clip_shares(rank, world):
     blk = logits[:, lo:hi]                                           # this rank's columns
     row_max = blk.max(dim=1).values
     row_sum = torch.exp(blk - row_max[:, None]).sum(dim=1)
-    row_lse = merge_row_softmax_stats(row_max, row_sum)
+    row_lse = merge_row_softmax_stats(row_max, row_sum, dist.group.WORLD)
     col_lse = torch.logsumexp(blk, dim=0)
     diag = blk[lo:hi].diag()
     share = ((row_lse[lo:hi] - diag) + (col_lse - diag)).sum() / (2 * Bg)

@@ -1,0 +1,114 @@
+"""Data-parallel correctness on ONE MI355X: two ranks (gloo rendezvous, both on cuda:0) each train on half
+of a batch with synchronised BatchNorm statistics, all-gathered speech embeddings (global negatives) and a
+SUM gradient all-reduce; loss, embeddings and gradients must equal the single-process run on the whole
+batch.  (The 8-GPU RCCL run is the driver's; this covers the algebra and the collective call sequence.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from oracle import brain_oracle as O      # noqa: E402
+
+
+class Args(dict):
+    __getattr__ = dict.__getitem__
+
+
+DIMS = dict(C=20, S=3, D1=32, D2=48, F=64, K=4, T=70)
+
+
+def build(dtype, P):
+    from speech_decoding.models import BrainEncoder
+    from speech_decoding.utils.loss import CLIPLoss
+    d = DIMS
+    loc = O.synthetic_positions(d["C"], seed=1)
+    args = Args(num_subjects=d["S"], D1=d["D1"], D2=d["D2"], F=d["F"], K=d["K"], dataset="Gwilliams2022", d_drop=0.1,
+                root_dir=".", preprocs={"last4layers": False}, reduction="mean", init_temperature=3.0,
+                sensor_positions=loc.numpy(), compute_dtype=dtype)
+    enc = BrainEncoder(args)
+    enc.load_state_dict(P)
+    return enc.to("cuda:0").train(), CLIPLoss(args).to("cuda:0")
+
+
+def grads_of(enc, lossf):
+    out = {n: (torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad).detach().cpu().clone()
+           for n, p in enc.named_parameters()}
+    out["temp"] = lossf.temp.grad.detach().cpu().clone()
+    return out
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from speech_decoding_amd.distributed import allreduce_gradients, shard_range
+        d = DIMS
+        loc = O.synthetic_positions(d["C"], seed=1)
+        P = O.seeded_params(d["C"], d["S"], d["D1"], d["D2"], d["F"], d["K"], seed=2, loc=loc)
+        Bg = 12 * world
+        X, Y, subj = O.synthetic_batch(Bg, d["C"], d["T"], d["F"], d["S"], seed=3)
+        lo, hi = shard_range(Bg, rank, world)
+        enc, lossf = build("fp32", P)
+        enc.set_drop_centre(4)
+        Z = enc(X[lo:hi].to("cuda:0"), subj[lo:hi])
+        Yl = Y[lo:hi].to("cuda:0")
+        loss = lossf(Yl, Z)
+        loss.backward()
+        allreduce_gradients(list(enc.parameters()) + list(lossf.parameters()))
+        from speech_decoding.models import Classifier
+        top = Classifier(None)(Z, Yl)                              # served from the loss's global ranks
+        top_again = Classifier(None)(Z, Yl.clone())                # uncached path: gathers and ranks globally
+        assert top == top_again
+        res = dict(loss=float(loss.detach()), Z=Z.detach().float().cpu(), grads=grads_of(enc, lossf), top=top,
+                   rm=enc.conv_blocks.conv2.batchnorm1.running_mean.cpu().clone())
+        if rank == 0:      # single-process reference on the whole batch, collectives switched off
+            enc1, lossf1 = build("fp32", P)
+            enc1.sync_batchnorm = False
+            lossf1.global_negatives = False
+            enc1.set_drop_centre(4)
+            Z1 = enc1(X.to("cuda:0"), subj)
+            l1 = lossf1(Y.to("cuda:0"), Z1)
+            l1.backward()
+            local_clf = Classifier(None)
+            local_clf.global_candidates = False
+            res["ref"] = dict(loss=float(l1.detach()), Z=Z1.detach().float().cpu(), grads=grads_of(enc1, lossf1),
+                              rm=enc1.conv_blocks.conv2.batchnorm1.running_mean.cpu().clone(),
+                              top=local_clf(Z1, Y.to("cuda:0")))
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process_global_batch():
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    out = dict(ret)
+    ref = out[0]["ref"]
+    B = 12
+    for r in range(world):
+        assert abs(out[r]["loss"] - ref["loss"]) < 2e-5                       # every rank reports the global loss
+        np.testing.assert_allclose(out[r]["Z"].numpy(), ref["Z"][r * B:(r + 1) * B].numpy(), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(out[r]["rm"].numpy(), ref["rm"].numpy(), rtol=1e-4, atol=1e-6)
+        for k, g in out[r]["grads"].items():
+            gr = ref["grads"][k]
+            scale = float(gr.abs().max()) + 1e-12
+            if k.startswith("conv_blocks.") and k.endswith((".conv0.bias", ".conv1.bias")):
+                continue
+            assert float((g - gr).abs().max()) <= 2e-3 * scale + 1e-7, (r, k)
+    # retrieval accuracy over the global batch = mean of the per-rank accuracies
+    top1 = np.mean([out[r]["top"][0] for r in range(world)])
+    top10 = np.mean([out[r]["top"][1] for r in range(world)])
+    assert (top1, top10) == pytest.approx(ref["top"])
