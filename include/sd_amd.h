@@ -34,7 +34,9 @@ extern "C" {
 enum { SDA_F32 = 0, SDA_BF16 = 1 };
 
 /* conv_gemm epilogue flags */
-enum { SDA_EPI_GELU = 1 };
+enum { SDA_EPI_GELU = 1,
+       SDA_CONV_SINGLE_TILE = 4096, /* force one 128-row tile per workgroup */
+       SDA_CONV_PAIR_TILES = 8192   /* force two tiles per workgroup (default: only for >= 512 tiles) */ };
 
 int sda_abi_version(void);
 const char* sda_last_error(void);

@@ -31,10 +31,11 @@ template <int TILE_CO> struct EpiGeom {
   static constexpr int RED_BYTES = RG * TILE_CO * 2 * 4;
 };
 
-template <int TILE_CO, int KS> constexpr int conv_stage_bytes() { return XS_BYTES + KS * TILE_CO * ROW_B; }
-template <int TILE_CO, int KS> constexpr int conv_lds_bytes() {
-  constexpr int main_b = 2 * conv_stage_bytes<TILE_CO, KS>();
-  constexpr int epi_b = EpiGeom<TILE_CO>::EP_BYTES + EpiGeom<TILE_CO>::RED_BYTES;
+template <int TILE_CO, int KS, int NT> constexpr int conv_stage_bytes() { return NT * XS_BYTES + KS * TILE_CO * ROW_B; }
+template <int NT, int KS> constexpr int conv_stages() { return (NT == 2 && KS == 3) ? 3 : 2; }
+template <int TILE_CO, int KS, int NT> constexpr int conv_lds_bytes() {
+  constexpr int main_b = conv_stages<NT, KS>() * conv_stage_bytes<TILE_CO, KS, NT>();
+  constexpr int epi_b = NT * (EpiGeom<TILE_CO>::EP_BYTES + EpiGeom<TILE_CO>::RED_BYTES);
   return main_b > epi_b ? main_b : epi_b;
 }
 
@@ -51,49 +52,58 @@ template <> __device__ inline float4 round_like<uint16_t>(float4 v) {
   return make_float4(bf2f(f2bf(v.x)), bf2f(f2bf(v.y)), bf2f(f2bf(v.z)), bf2f(f2bf(v.w)));
 }
 
-template <typename E, int TILE_CO, int KS>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a, const int n_t_tiles) {
+// NT = number of 128-row output tiles one workgroup computes SIDE BY SIDE against the same weight slab
+// (4 waves per tile).  The weight slab is 3/4 of the bytes a workgroup pulls through LDS per K-step, so
+// NT = 2 cuts the L2->LDS traffic per FLOP by 37 %: the main loop is LDS-DMA bound, not MFMA bound.
+template <typename E, int TILE_CO, int KS, int NT>
+__global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_args a, const int n_t_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SLAB = ROW_B / (int)sizeof(E);          // input channels per LDS row / K-step
   constexpr int PER16 = Elem<E>::PER16;
   constexpr int NREP = TILE_CO / 32;
   constexpr int HALF_CO = TILE_CO / 2;
-  constexpr int STAGE = conv_stage_bytes<TILE_CO, KS>();
-  constexpr int W_PIECES = KS * TILE_CO / 16;           // 1 KB pieces = 16 rows x 64 B
+  constexpr int STAGE = conv_stage_bytes<TILE_CO, KS, NT>();
+  constexpr int NW = 4 * NT;                            // waves per workgroup
+  constexpr int TP = TILE_CO / 16;                      // 1 KB weight pieces per tap (16 rows x 64 B)
   using G = EpiGeom<TILE_CO>;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_t = wid >> 1, wave_c = wid & 1;
+  const int tsel = wid >> 2;                            // which of the NT tiles this wave works on
+  const int wave_t = (wid >> 1) & 1, wave_c = wid & 1;
   const int lr = lane & 15, lq = lane >> 4;
 
   int bid = blockIdx.x;
   const int n_co = a.Cout_p / TILE_CO;
-  // XCD-aware order (blocks i and i+8 share an XCD/L2): the n_co tiles that read the same input rows are
-  // dealt to the same XCD.  Pure speed: any placement is correct.
+  // XCD-aware order (blocks i and i+8 share an XCD/L2): the n_co workgroups that read the same input rows
+  // are dealt to the same XCD.  Pure speed: any placement is correct.
   int co_tile;
   {
     const int group = 8 * n_co, full = (int)(gridDim.x / group) * group;
     if (bid < full) {
       const int base = bid / group * group, rem = bid - base;
       co_tile = rem / 8;
-      bid = (base + (rem & 7) * n_co + co_tile) / n_co;      // = base / n_co + (rem & 7)
+      bid = base / n_co + (rem & 7);
     } else {
       co_tile = bid % n_co; bid /= n_co;
     }
   }
-  const int t_tile = bid % n_t_tiles; bid /= n_t_tiles;
-  const int b = bid % a.B;
-  const int ks = bid / a.B;
+  const int tiles_total = a.B * n_t_tiles;
+  const int groups_total = (tiles_total + NT - 1) / NT;
+  const int ks = bid / groups_total;
+  const int tt = (bid - ks * groups_total) * NT + tsel;   // linear (sample, t-tile) index of this wave's tile
+  const bool tile_ok = tt < tiles_total;
+  const int b = tile_ok ? tt / n_t_tiles : 0;
+  const int t_tile = tile_ok ? tt - b * n_t_tiles : 0;
   const int co0 = co_tile * TILE_CO;
   const int t0 = t_tile * TILE_T;
   const int dil = a.dil;
   const int halo = (KS == 3) ? dil : 0;
 
   const E* __restrict__ xg = reinterpret_cast<const E*>(a.x);
-  const int wsel = a.widx ? a.widx[b] : 0;
+  const int wsel = a.widx ? a.widx[b] : 0;              // per-sample weights are launched with NT == 1
   const E* __restrict__ wg = reinterpret_cast<const E*>(a.w) + (size_t)wsel * KS * a.Cout_p * a.w_pitch;
-  const long row_base = a.x_row0 + (long)b * a.x_sample_rows + t0 - halo;   // LDS x row 0
+  const long row_base = a.x_row0 + (long)b * a.x_sample_rows + t0 - halo;   // LDS x row 0 of this wave's tile
   const int x_pieces = (TILE_T + 2 * halo + 15) >> 4;                       // 16-row pieces actually needed
 
   f32x4 acc[4][NREP];
@@ -107,75 +117,137 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
   const int s_begin = ks * per_split;
   const int s_end = (a.flags & 512) ? s_begin : min(nslab, s_begin + per_split);
 
-  // Per-lane source offsets of the LDS-DMA pieces.  A piece is one wave-instruction: 64 lanes x 16 B land
-  // lane-linearly in LDS (16 rows x 64 B), so the swizzle goes on the SOURCE chunk.  Rows outside the
-  // operand (only possible in split-K matrix mode) are clamped: they feed outputs that are never stored.
+  // LDS-DMA pieces.  A piece is one wave-instruction: 64 lanes x 16 B land lane-linearly in LDS (16 rows x
+  // 64 B), so the swizzle goes on the SOURCE chunk.  Rows outside the operand (only possible in split-K
+  // matrix mode) are clamped: they feed outputs that are never stored.  The 4 waves of a tile fetch that
+  // tile's input rows; all NW waves share the weight pieces, issued tap by tap between MFMA groups.
   const int prow = lane >> 2;                                   // row within the piece
   const int pchunk = lane & 3;                                  // physical chunk written by this lane
-  // x pieces: wave w takes pieces w, w+4, ...; w pieces likewise.  `part`/`nparts` split a slab's DMA
-  // issue into KS interleavable portions so the issue cost hides behind the MFMAs of the current slab.
   auto stage_x = [&](int s, int buf) {
-    unsigned char* xs = smem + buf * STAGE;
+    unsigned char* xs = smem + buf * STAGE + tsel * XS_BYTES;
     const size_t koff = (size_t)s * SLAB;
-    for (int p = wid; p < x_pieces; p += 4) {
-      const int r = p * 16 + prow;
-      long row = row_base + r;
-      row = row < 0 ? 0 : (row >= a.x_rows_limit ? a.x_rows_limit - 1 : row);
-      const int lc = (pchunk ^ (r >> 2)) & 3;
-      __builtin_amdgcn_global_load_lds((gmem_cv*)(xg + (size_t)row * a.x_pitch + koff + lc * PER16),
-                                       (lds_v*)(xs + p * 1024), 16, 0, 0);
+    if (tile_ok) {
+      for (int p = wid & 3; p < x_pieces; p += 4) {
+        const int r = p * 16 + prow;
+        long row = row_base + r;
+        row = row < 0 ? 0 : (row >= a.x_rows_limit ? a.x_rows_limit - 1 : row);
+        const int lc = (pchunk ^ (r >> 2)) & 3;
+        lds_dma16(xg + (size_t)row * a.x_pitch + koff + lc * PER16,
+                  __builtin_amdgcn_readfirstlane(lds_addr(xs + p * 1024)));
+      }
     }
   };
   auto stage_w = [&](int s, int buf, int tap) {          // the TILE_CO rows of one tap
-    unsigned char* ws = smem + buf * STAGE + XS_BYTES;
+    unsigned char* ws = smem + buf * STAGE + NT * XS_BYTES;
     const size_t koff = (size_t)s * SLAB;
-    constexpr int TP = TILE_CO / 16;                      // pieces per tap
 #pragma unroll
-    for (int i = 0; i < (TP + 3) / 4; ++i) {
-      const int q = wid + i * 4;
+    for (int i = 0; i < (TP + NW - 1) / NW; ++i) {
+      const int q = wid + i * NW;
       if (q < TP) {
         const int r = tap * TILE_CO + q * 16 + prow;      // row of the [tap][co] weight image
         int co = co0 + q * 16 + prow;
         co = co < a.w_rows_limit ? co : a.w_rows_limit - 1;
         const int lc = (pchunk ^ (r >> 2)) & 3;
-        __builtin_amdgcn_global_load_lds((gmem_cv*)(wg + ((size_t)tap * a.Cout_p + co) * a.w_pitch + koff + lc * PER16),
-                                         (lds_v*)(ws + (tap * TP + q) * 1024), 16, 0, 0);
+        lds_dma16(wg + ((size_t)tap * a.Cout_p + co) * a.w_pitch + koff + lc * PER16,
+                  __builtin_amdgcn_readfirstlane(lds_addr(ws + (tap * TP + q) * 1024)));
       }
     }
   };
 
-  if (s_begin < s_end) {
-    stage_x(s_begin, 0);
+  constexpr int NS = conv_stages<NT, KS>();
+  auto compute_tap = [&](const unsigned char* xs, const unsigned char* ws, int tap, auto&& between) {
+    uint4 af[4], bf[NREP];
+    const int xrow = wave_t * 64 + lr + tap * dil;
+    const int wrow = tap * TILE_CO + wave_c * HALF_CO + lr;
 #pragma unroll
-    for (int tap = 0; tap < KS; ++tap) stage_w(s_begin, 0, tap);
-  }
-  for (int s = s_begin; s < s_end; ++s) {
-    const int cur = (s - s_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of slab s have landed
-    __syncthreads();                                    // ... everybody's have, and slab s-1 is fully consumed
-    const bool more = s + 1 < s_end;
-    if (more) stage_x(s + 1, cur ^ 1);                  // DMA of the next slab overlaps the MFMAs below
-    const unsigned char* xs = smem + cur * STAGE;
-    const unsigned char* ws = xs + XS_BYTES;
+    for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow + m * 16, lq));
 #pragma unroll
-    for (int tap = 0; tap < KS; ++tap) {
-      uint4 af[4], bf[NREP];
-      const int xrow = wave_t * 64 + lr + tap * dil;
-      const int wrow = tap * TILE_CO + wave_c * HALF_CO + lr;
+    for (int n = 0; n < NREP; ++n) bf[n] = *reinterpret_cast<const uint4*>(ws + lds_sw64(wrow + n * 16, lq));
+    between();                                          // next slab's DMA issue, hidden behind the MFMAs below
 #pragma unroll
-      for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow + m * 16, lq));
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int n = 0; n < NREP; ++n) bf[n] = *reinterpret_cast<const uint4*>(ws + lds_sw64(wrow + n * 16, lq));
-      if (more) stage_w(s + 1, cur ^ 1, tap);           // issue this tap's share of the next slab between MFMA groups
+      for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af[m], bf[n], acc[m][n]);
+  };
+
+  if constexpr (NS == 2) {
+    if (s_begin < s_end) {
+      stage_x(s_begin, 0);
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int tap = 0; tap < KS; ++tap) stage_w(s_begin, 0, tap);
+    }
+    for (int s = s_begin; s < s_end; ++s) {
+      const int cur = (s - s_begin) & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of slab s have landed
+      __builtin_amdgcn_s_barrier();                       // ... everybody's have, and slab s-1 is fully consumed
+      const bool more = s + 1 < s_end;
+      if (more) stage_x(s + 1, cur ^ 1);                  // DMA of the next slab overlaps the MFMAs below
+      const unsigned char* xs = smem + cur * STAGE + tsel * XS_BYTES;
+      const unsigned char* ws = smem + cur * STAGE + NT * XS_BYTES;
 #pragma unroll
-        for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af[m], bf[n], acc[m][n]);
+      for (int tap = 0; tap < KS; ++tap)
+        compute_tap(xs, ws, tap, [&] { if (more) stage_w(s + 1, cur ^ 1, tap); });
+    }
+  } else {
+    // Three LDS stages, two slabs in flight: every wave issues EXACTLY 3 input pieces + 4 weight pieces per
+    // slab (indices clamped, duplicates rewrite identical bytes), so a counted s_waitcnt vmcnt(7) retires
+    // slab s while slab s+1 stays in flight across the raw s_barrier (a __syncthreads() would drain it).
+    constexpr int WQ = 4;                                 // weight pieces per wave per slab: KS*TP = 30 <= 8*4
+    static_assert(KS * TP <= NW * WQ, "weight pieces do not fit the fixed per-wave DMA count");
+    auto stage3_x = [&](int s, int buf) {
+      unsigned char* xs = smem + buf * STAGE + tsel * XS_BYTES;
+      const size_t koff = (size_t)s * SLAB;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        int p = (wid & 3) + 4 * i;
+        p = p < x_pieces ? p : x_pieces - 1;
+        const int r = p * 16 + prow;
+        long row = row_base + r;
+        row = row < 0 ? 0 : (row >= a.x_rows_limit ? a.x_rows_limit - 1 : row);
+        const int lc = (pchunk ^ (r >> 2)) & 3;
+        lds_dma16(xg + (size_t)row * a.x_pitch + koff + lc * PER16,
+                  __builtin_amdgcn_readfirstlane(lds_addr(xs + p * 1024)));
+      }
+    };
+    auto stage3_w = [&](int s, int buf, int i) {          // i-th of this wave's WQ weight pieces
+      unsigned char* ws = smem + buf * STAGE + NT * XS_BYTES;
+      const size_t koff = (size_t)s * SLAB;
+      int q = wid + NW * i;
+      q = q < KS * TP ? q : KS * TP - 1;
+      const int tap = q / TP;
+      const int r = q * 16 + prow;                        // row of the [tap][co] weight image (= tap*TILE_CO + ...)
+      const int co = co0 + (q - tap * TP) * 16 + prow;
+      const int lc = (pchunk ^ (r >> 2)) & 3;
+      lds_dma16(wg + ((size_t)tap * a.Cout_p + co) * a.w_pitch + koff + lc * PER16,
+                  __builtin_amdgcn_readfirstlane(lds_addr(ws + q * 1024)));
+    };
+    auto stage3 = [&](int s, int buf) {
+      stage3_x(s, buf);
+#pragma unroll
+      for (int i = 0; i < WQ; ++i) stage3_w(s, buf, i);
+    };
+    if (s_begin < s_end) stage3(s_begin, 0);
+    if (s_begin + 1 < s_end) stage3(s_begin + 1, 1);
+    int cur = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+      if (s + 1 < s_end) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const bool more = s + 2 < s_end;
+      const int nxt = cur >= 1 ? cur - 1 : 2;             // (cur + 2) % 3
+      if (more) stage3_x(s + 2, nxt);
+      const unsigned char* xs = smem + cur * STAGE + tsel * XS_BYTES;
+      const unsigned char* ws = smem + cur * STAGE + NT * XS_BYTES;
+      compute_tap(xs, ws, 0, [&] { if (more) stage3_w(s + 2, nxt, 0); });
+      compute_tap(xs, ws, 1, [&] { if (more) stage3_w(s + 2, nxt, 1); });
+      compute_tap(xs, ws, 2, [&] { if (more) { stage3_w(s + 2, nxt, 2); stage3_w(s + 2, nxt, 3); } });
+      cur = cur == 2 ? 0 : cur + 1;
     }
   }
 
   // ------------------------------------------------------------------ split-K: raw fp32 partials
   if (a.partial) {
+    if (!tile_ok) return;
     float* __restrict__ pp = a.partial + (size_t)ks * a.T * a.Cout_p;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -210,10 +282,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
         for (int r = 0; r < 4; ++r) acc[m][n][r] += bv;
     }
   }
-  float* ep = reinterpret_cast<float*>(smem);
-  float* red = reinterpret_cast<float*>(smem + G::EP_BYTES);
-  const int chunk = tid % G::NCH, rg = tid / G::NCH;
-  const bool active = rg < G::RG;
+  // each tile's 4 waves run their own epilogue in a private LDS region (barriers are workgroup-wide)
+  float* ep = reinterpret_cast<float*>(smem + tsel * (G::EP_BYTES + G::RED_BYTES));
+  float* red = reinterpret_cast<float*>(smem + tsel * (G::EP_BYTES + G::RED_BYTES) + G::EP_BYTES);
+  const int ltid = tid & 255;
+  const int chunk = ltid % G::NCH, rg = ltid / G::NCH;
+  const bool active = (rg < G::RG) && tile_ok;
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   E* __restrict__ yg = reinterpret_cast<E*>(a.y);
   E* __restrict__ ypre = reinterpret_cast<E*>(a.y_pre);
@@ -277,20 +351,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const sda_conv_args a
       }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * TILE_CO; i += 256) {
-      const int which = i / TILE_CO, c = i - which * TILE_CO;
-      float s = 0.f;
-      for (int g = 0; g < G::RG; ++g) s += red[(g * 2 + which) * TILE_CO + c];
-      a.stats[((size_t)(b * n_t_tiles + t_tile) * 2 + which) * a.Cout_p + co0 + c] = s;
+    if (tile_ok) {
+      for (int i = ltid; i < 2 * TILE_CO; i += 256) {
+        const int which = i / TILE_CO, c = i - which * TILE_CO;
+        float s = 0.f;
+        for (int g = 0; g < G::RG; ++g) s += red[(g * 2 + which) * TILE_CO + c];
+        a.stats[((size_t)tt * 2 + which) * a.Cout_p + co0 + c] = s;
+      }
     }
   }
 }
 
-template <typename E, int TILE_CO, int KS>
+template <typename E, int TILE_CO, int KS, int NT>
 static int launch_conv(const sda_conv_args& a, hipStream_t st) {
-  constexpr int lds = conv_lds_bytes<TILE_CO, KS>();
+  constexpr int lds = conv_lds_bytes<TILE_CO, KS, NT>();
   static bool attr_done = false;
-  auto kern = conv_gemm_kernel<E, TILE_CO, KS>;
+  auto kern = conv_gemm_kernel<E, TILE_CO, KS, NT>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             lds) != hipSuccess) {
@@ -300,17 +376,29 @@ static int launch_conv(const sda_conv_args& a, hipStream_t st) {
     attr_done = true;
   }
   const int n_t = (a.T + TILE_T - 1) / TILE_T;
-  const long grid = (long)(a.Cout_p / TILE_CO) * n_t * a.B * a.ksplit;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a, n_t);
+  const long groups = ((long)a.B * n_t + NT - 1) / NT;
+  const long grid = (long)(a.Cout_p / TILE_CO) * groups * a.ksplit;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256 * NT), lds, st, a, n_t);
   return check_launch("conv_gemm");
+}
+
+template <typename E, int TILE_CO>
+static int dispatch_conv_nt(const sda_conv_args& a, hipStream_t st) {
+  const bool k3 = a.KS == 3;
+  const int n_t = (a.T + TILE_T - 1) / TILE_T;
+  // two tiles per workgroup whenever tiles are independent of per-sample weights and there are enough of them
+  // (1x1 convs stage a small weight slab and are epilogue/HBM bound: pairing only costs them occupancy)
+  const bool pair = !a.widx && a.ksplit == 1 && !(a.flags & SDA_CONV_SINGLE_TILE) &&
+                    ((k3 && (long)a.B * n_t >= 512) || (a.flags & SDA_CONV_PAIR_TILES));
+  if (pair) return k3 ? launch_conv<E, TILE_CO, 3, 2>(a, st) : launch_conv<E, TILE_CO, 1, 2>(a, st);
+  return k3 ? launch_conv<E, TILE_CO, 3, 1>(a, st) : launch_conv<E, TILE_CO, 1, 1>(a, st);
 }
 
 template <typename E>
 static int dispatch_conv(const sda_conv_args& a, hipStream_t st) {
-  const bool k3 = a.KS == 3;
-  if (a.Cout_p % 160 == 0) return k3 ? launch_conv<E, 160, 3>(a, st) : launch_conv<E, 160, 1>(a, st);
-  if (a.Cout_p % 128 == 0) return k3 ? launch_conv<E, 128, 3>(a, st) : launch_conv<E, 128, 1>(a, st);
-  return k3 ? launch_conv<E, 64, 3>(a, st) : launch_conv<E, 64, 1>(a, st);
+  if (a.Cout_p % 160 == 0) return dispatch_conv_nt<E, 160>(a, st);
+  if (a.Cout_p % 128 == 0) return dispatch_conv_nt<E, 128>(a, st);
+  return dispatch_conv_nt<E, 64>(a, st);
 }
 
 }  // namespace sda

@@ -104,6 +104,22 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// LDS-DMA (global_load_lds_dwordx4) issued through inline asm.  hipcc treats the builtin form as an LDS
+// write that may alias every later ds_read of the same array and drains it with s_waitcnt vmcnt(0) before the
+// first read — which serialises the copy of slab s+1 against the MFMAs of slab s.  The asm form is invisible
+// to that bookkeeping: completion is enforced by OUR counted s_waitcnt vmcnt(N) + barrier.
+//   gsrc: this lane's 16 source bytes; lds_dst: wave-uniform LDS byte address; lane l lands at lds_dst + 16*l.
+__device__ inline void lds_dma16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ inline uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const void*)p);
+}
+
 // host-side error plumbing (capi.hip)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);

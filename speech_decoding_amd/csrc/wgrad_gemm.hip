@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
         const int r = byte / G::RB_M;
         const int c = ((byte - r * G::RB_M) >> 4) ^ chunk_xor<E, G::RB_M>(r);
         const long row = (t0 + r < a.T) ? (srow + t0 + r) : a.dy_zero_row;
-        __builtin_amdgcn_global_load_lds((gmem_cv*)(dyg + (size_t)row * a.dy_pitch + co0 + c * PER16),
-                                         (lds_v*)(dys + p * 1024), 16, 0, 0);
+        lds_dma16(dyg + (size_t)row * a.dy_pitch + co0 + c * PER16,
+                  __builtin_amdgcn_readfirstlane(lds_addr(dys + p * 1024)));
       }
     }
     for (int p = wid; p < x_pieces; p += 4) {
@@ -157,16 +157,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
       const int c = ((byte - r * G::RB_N) >> 4) ^ chunk_xor<E, G::RB_N>(r);
       long row = srow + t0 - halo + r;
       row = row < 0 ? 0 : (row >= a.rows_limit ? a.rows_limit - 1 : row);
-      __builtin_amdgcn_global_load_lds((gmem_cv*)(xg + (size_t)row * a.x_pitch + ci0 + c * PER16),
-                                       (lds_v*)(xs + p * 1024), 16, 0, 0);
+      lds_dma16(xg + (size_t)row * a.x_pitch + ci0 + c * PER16,
+                  __builtin_amdgcn_readfirstlane(lds_addr(xs + p * 1024)));
     }
   };
 
   if (total > 0) stage(0, 0);
   for (int it = 0; it < total; ++it) {
     const int cur = it & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own DMA pieces of chunk `it` landed (asm DMA: not tracked by hipcc)
+    __builtin_amdgcn_s_barrier();                       // everyone's landed; chunk it-1 fully consumed
     if (it + 1 < total) stage(it + 1, cur ^ 1);
     const unsigned char* dys = smem + cur * G::STAGE;
     const unsigned char* xs = dys + G::DY_BYTES;

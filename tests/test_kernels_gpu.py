@@ -73,12 +73,13 @@ def test_pack_unpack_roundtrip_and_padding(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tiling", [4096, 8192])          # one tile / two tiles per workgroup
 @pytest.mark.parametrize("cin,cout,dil,T", [(40, 48, 1, 40), (270, 320, 2, 300), (320, 320, 16, 360),
                                             (96, 128, 8, 130), (64, 640, 4, 129)])
-def test_conv3_forward_bias_residual_stats(ops, dtype, cin, cout, dil, T):
+def test_conv3_forward_bias_residual_stats(ops, dtype, cin, cout, dil, T, tiling):
     from speech_decoding_amd import lib as L
     g = torch.Generator().manual_seed(cin + cout + dil)
-    B = 2
+    B = 3 if tiling == 8192 else 2                        # odd tile counts leave a half-empty workgroup
     x = q(torch.randn(B, cin, T, generator=g), dtype)
     w = q(torch.randn(cout, cin, 3, generator=g) / math.sqrt(3 * cin), dtype)
     bias = torch.randn(cout, generator=g)
@@ -92,7 +93,7 @@ def test_conv3_forward_bias_residual_stats(ops, dtype, cin, cout, dil, T):
     yb = ops.new_rows(B, T, Cout_p, dtype, DEV)
     stats = torch.zeros((B * ops.n_t_tiles(T), 2, Cout_p), device=DEV)
     ops.conv_gemm(xb, wp, yb, B=B, T=T, KS=3, dil=dil, bias=ops.pack_vector(bias.to(DEV), Cout_p),
-                  res=xb if use_res else None, stats=stats)
+                  res=xb if use_res else None, stats=stats, dbg_flags=tiling)
     got = from_rows(ops, yb, B, cout, T)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), **tol(dtype, 3 * cin))
     # pad rows / channels of the output stay zero
