@@ -137,16 +137,16 @@ __global__ void unpack_vector_kernel(const float* __restrict__ g, float* __restr
 // ------------------------------------------------------------------------------------------------
 // BatchNorm1d: finalize / apply+GELU / backward   (models.py:135,143,158,161)
 // ------------------------------------------------------------------------------------------------
-// Sum partial[k][which][c] over k for the 16 channels of this block: 16 thread groups stride over k,
-// fp64 accumulation, fixed combination order (deterministic).  Result valid for threadIdx.x < 16.
+// Sum partial[k][which][c] over k for the 8 channels of this block: 32 thread groups stride over k,
+// fp64 accumulation, fixed combination order (deterministic).  Result valid for threadIdx.x < 8.
 __device__ inline void block_partial_sums(const float* __restrict__ partial, int n, int Cp, int c, bool two,
                                           double& s0, double& s1) {
-  __shared__ double sh[2][16][16];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  __shared__ double sh[2][32][8];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
   double a0 = 0.0, a1 = 0.0;
   if (c < Cp) {
-#pragma unroll 4
-    for (int k = ty; k < n; k += 16) {
+#pragma unroll 8
+    for (int k = ty; k < n; k += 32) {
       a0 += (double)partial[((size_t)k * 2 + 0) * Cp + c];
       if (two) a1 += (double)partial[((size_t)k * 2 + 1) * Cp + c];
     }
@@ -157,7 +157,7 @@ __device__ inline void block_partial_sums(const float* __restrict__ partial, int
   s0 = 0.0; s1 = 0.0;
   if (ty == 0) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) { s0 += sh[0][g][tx]; s1 += sh[1][g][tx]; }
+    for (int g = 0; g < 32; ++g) { s0 += sh[0][g][tx]; s1 += sh[1][g][tx]; }
   }
 }
 
@@ -165,10 +165,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* mean_o,
                                    float* rstd_o, float* scale_o, float* shift_o, int C, int Cp, int training) {
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double s = 0.0, q = 0.0;
   if (training) block_partial_sums(partial, ntiles, Cp, c, true, s, q);
-  if (threadIdx.x >= 16 || c >= Cp) return;
+  if (threadIdx.x >= 8 || c >= Cp) return;
   if (c >= C) { mean_o[c] = 0.f; rstd_o[c] = 0.f; scale_o[c] = 0.f; shift_o[c] = 0.f; return; }
   double mean, var;
   if (training) {
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_gelu_fwd_kernel(const E* __restrict__ 
   }
 }
 
-constexpr int RED_MAX_BLOCKS = 512;
+constexpr int RED_MAX_BLOCKS = 1024;
 
 // Column reductions over valid rows.  MODE 0: sum x (bias grads).  MODE 1: BN+GELU backward sums
 // (dg, dg * xhat) with dg = dy * GELU'(gamma * xhat + beta).
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
         ga[j] = c < C ? gamma[c] : 0.f; be[j] = c < C ? beta[c] : 0.f;
       }
     }
+#pragma unroll 4
     for (size_t r = r0 + rg; r < r1; r += RG) {
       const int b = r / T, t = r - (size_t)b * T;
       const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
@@ -343,10 +344,10 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
 // sums[which][c] = sum over blocks (fp64, fixed order)
 __global__ __launch_bounds__(256) void col_reduce_final_kernel(const float* __restrict__ partial, int nblocks,
                                                                float* __restrict__ out0, float* __restrict__ out1, int Cp) {
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double s0, s1;
   block_partial_sums(partial, nblocks, Cp, c, out1 != nullptr, s0, s1);
-  if (threadIdx.x >= 16 || c >= Cp) return;
+  if (threadIdx.x >= 8 || c >= Cp) return;
   out0[c] = (float)s0;
   if (out1) out1[c] = (float)s1;
 }
@@ -472,7 +473,7 @@ static inline int ew_grid(size_t total) {
 
 static int red_blocks(int B, int T) {
   long rows = (long)B * T;
-  long nb = (rows + 63) / 64;
+  long nb = (rows + 31) / 32;
   if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
   if (nb < 1) nb = 1;
   return (int)nb;
@@ -555,7 +556,7 @@ extern "C" int sda_bn_finalize(const float* partial, int ntiles, double count, c
   if (!gamma || !beta || !mean || !rstd || !scale || !shift || C > Cp) { set_error("bn_finalize: bad arguments"); return -1; }
   if (training && (!partial || ntiles < 1 || count < 1.0)) { set_error("bn_finalize: training mode needs partial statistics"); return -1; }
   if (!training && (!running_mean || !running_var)) { set_error("bn_finalize: eval mode needs running statistics"); return -1; }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, ntiles, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, ntiles, count,
                      gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, C, Cp, training);
   return check_launch("bn_finalize");
 }
@@ -583,7 +584,7 @@ extern "C" int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const 
   const size_t lds = (size_t)RG * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((col_reduce_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)dy,
                                          (const E*)x, mean, rstd, gamma, beta, C, partial, B, T, Cp));
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 15) / 16), dim3(256), 0, st, partial, nb, dbeta, dgamma, Cp);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, partial, nb, dbeta, dgamma, Cp);
   return check_launch("bn_gelu_backward_reduce");
 }
 
@@ -612,7 +613,7 @@ extern "C" int sda_colsum(const void* x, float* out, float* scratch, int B, int 
   const size_t lds = (size_t)RG * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((col_reduce_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)x,
                                          (const E*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, B, T, Cp));
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 15) / 16), dim3(256), 0, st, scratch, nb, out, (float*)nullptr, Cp);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, scratch, nb, out, (float*)nullptr, Cp);
   return check_launch("colsum");
 }
 
@@ -650,7 +651,7 @@ extern "C" int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, 
   const size_t lds = (size_t)(256 / (Ch / 4)) * 2 * Ch * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)x,
                                          (const E*)dy, (E*)dx, scratch, B, T, Ch));
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 15) / 16), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
   return check_launch("glu_backward_colsum");
 }
 
@@ -662,7 +663,7 @@ extern "C" int sda_gelu_backward_colsum(const void* u, const void* dz, void* du,
   const size_t lds = (size_t)(256 / (Cp / 4)) * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)u,
                                          (const E*)dz, (E*)du, scratch, B, T, Cp));
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 15) / 16), dim3(256), 0, st, scratch, nb, colsum, (float*)nullptr, Cp);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, (float*)nullptr, Cp);
   return check_launch("gelu_backward_colsum");
 }
 

@@ -109,9 +109,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
 
   int bid = blockIdx.x;
   const int n_n = a.Cin_p / WG_TN, n_m = a.Cout_p / TILE_M;
-  const int n_tile = bid % n_n; bid /= n_n;
-  const int m_tile = bid % n_m; bid /= n_m;
-  const int seg = bid;
+  // XCD-aware order (blocks i and i+8 share an XCD/L2): all output tiles of one sample segment run on the
+  // same XCD back to back, so the dy / x rows they all stream are fetched from HBM once and re-read from
+  // that XCD's L2 (measured: 5x fewer fabric bytes than the tile-fastest order).  Pure speed.
+  int seg, tile;
+  {
+    const int ntile = n_n * n_m, group = 8 * ntile, full = (int)(gridDim.x / group) * group;
+    if (bid < full) {
+      const int base = bid / group, rem = bid - base * group;
+      seg = base * 8 + (rem & 7);
+      tile = rem >> 3;
+    } else {
+      const int rem = bid - full;
+      seg = full / ntile + rem / ntile;
+      tile = rem % ntile;
+    }
+  }
+  const int n_tile = tile % n_n, m_tile = tile / n_n;
   const int co0 = m_tile * TILE_M, ci0 = n_tile * WG_TN;
   const int halo = (KS == 3) ? a.dil : 0;
   const int x_pieces = ((KT + 2 * halo) * G::RB_N + 1023) >> 10;

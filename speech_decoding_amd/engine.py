@@ -99,7 +99,9 @@ class EncoderEngine:
         self._ws.clear()
 
     def _uniform_segments(self, B: int, ntiles: int, device):
-        nseg = int(max(1, min(B, round(self.wgrad_target_wgs / max(1, ntiles)))))
+        # segments are dealt round-robin to the 8 XCDs (wgrad_gemm's block order), so use a multiple of 8
+        nseg = 8 * max(1, round(self.wgrad_target_wgs / (8 * max(1, ntiles))))
+        nseg = int(min(B, nseg)) if B >= 8 else int(max(1, min(B, nseg)))
         key = (B, nseg, str(device))
         if key not in self._seg_cache:
             edges = np.floor(np.linspace(0, B, nseg + 1)).astype(np.int32)
