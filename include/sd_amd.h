@@ -36,7 +36,7 @@ enum { SDA_F32 = 0, SDA_BF16 = 1 };
 /* conv_gemm epilogue flags */
 enum { SDA_EPI_GELU = 1,
        SDA_CONV_SINGLE_TILE = 4096, /* force one 128-row tile per workgroup */
-       SDA_CONV_PAIR_TILES = 8192   /* force two tiles per workgroup (default: only for >= 512 tiles) */ };
+       SDA_CONV_PAIR_TILES = 8192   /* two tiles per workgroup sharing one weight slab (default: one) */ };
 
 int sda_abi_version(void);
 const char* sda_last_error(void);
@@ -145,6 +145,7 @@ typedef struct sda_wgrad_args {
   void* out_e;          /* optional typed output [Cout rows][out_pitch] */
   const void* sub;      /* optional [Cout rows][out_pitch] */
   const float* rscale;  /* optional [Cout] */
+  const float* out_scale; /* optional device scalar multiplying the typed output (incoming dloss) */
   const int32_t* perm;
   const int32_t* seg_start; /* device int32 [nseg + 1] */
   int nseg, B, T, Cout_p, Cin_p, KS, dil;

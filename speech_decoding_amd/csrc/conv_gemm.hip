@@ -387,9 +387,10 @@ static int dispatch_conv_nt(const sda_conv_args& a, hipStream_t st) {
   const bool k3 = a.KS == 3;
   const int n_t = (a.T + TILE_T - 1) / TILE_T;
   // two tiles per workgroup whenever tiles are independent of per-sample weights and there are enough of them
-  // (1x1 convs stage a small weight slab and are epilogue/HBM bound: pairing only costs them occupancy)
-  const bool pair = !a.widx && a.ksplit == 1 && !(a.flags & SDA_CONV_SINGLE_TILE) &&
-                    ((k3 && (long)a.B * n_t >= 512) || (a.flags & SDA_CONV_PAIR_TILES));
+  // Two tiles per workgroup (shared weight slab, 3-stage counted-vmcnt pipeline) measure the same as one
+  // tile x two workgroups per CU once the LDS-DMA is asm-issued (both are bound by DMA bytes in flight per
+  // CU), so the single-tile form is the default; SDA_CONV_PAIR_TILES selects the paired form.
+  const bool pair = !a.widx && a.ksplit == 1 && (a.flags & SDA_CONV_PAIR_TILES) && !(a.flags & SDA_CONV_SINGLE_TILE);
   if (pair) return k3 ? launch_conv<E, TILE_CO, 3, 2>(a, st) : launch_conv<E, TILE_CO, 1, 2>(a, st);
   return k3 ? launch_conv<E, TILE_CO, 3, 1>(a, st) : launch_conv<E, TILE_CO, 1, 1>(a, st);
 }

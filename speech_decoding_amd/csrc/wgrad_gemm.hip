@@ -16,7 +16,6 @@
 
 namespace sda {
 
-constexpr int WG_TN = 64;       // ci columns per workgroup
 
 // Rows staged per K-chunk = two MFMA K-steps: 64 rows (bf16, 32 per step) / 32 rows (fp32, 16 per step).
 template <typename E> struct WK;
@@ -80,24 +79,28 @@ template <int RB> struct TrOp<float, RB> {
   __device__ static uint4 get(const unsigned char* img, int row0, int col0, int lane) { return tr_operand_f32<RB>(img, row0, col0, lane); }
 };
 
-template <typename E, int TILE_M, int KS> struct WGeom {
+// TN = ci columns per workgroup: 64 for KS = 3 (three accumulator sets), 128 for KS = 1 (wave tile
+// TILE_M/2 x 64: fewer LDS bytes per MFMA and half as many re-reads of dy).
+template <typename E, int TILE_M, int KS, int TN> struct WGeom {
   static constexpr int KT = WK<E>::KT;
   static constexpr int RB_M = TILE_M * (int)sizeof(E);          // dy image row bytes
-  static constexpr int RB_N = WG_TN * (int)sizeof(E);           // x image row bytes
+  static constexpr int RB_N = TN * (int)sizeof(E);              // x image row bytes
   static constexpr int DY_BYTES = KT * RB_M;
   static constexpr int XR = KT + 2 * PAD;
   static constexpr int X_BYTES = XR * RB_N;
   static constexpr int STAGE = DY_BYTES + X_BYTES;
   static constexpr int DY_PIECES = DY_BYTES / 1024;
-  static constexpr int EPI_BYTES = TILE_M * (WG_TN + 4) * 4;
+  static constexpr int EPI_BYTES = TILE_M * (TN + 4) * 4;
   static constexpr int LDS = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
   static_assert(DY_BYTES % 1024 == 0 && X_BYTES % 1024 == 0, "images must be whole 1 KB pieces");
 };
 
-template <typename E, int TILE_M, int KS>
+template <typename E, int TILE_M, int KS, int TN>
 __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using G = WGeom<E, TILE_M, KS>;
+  using G = WGeom<E, TILE_M, KS, TN>;
+  constexpr int WG_TN = TN;
+  constexpr int NREP = TN / 32;                             // 16-column n tiles per wave (wave tile = TILE_M/2 x TN/2)
   constexpr int PER16 = Elem<E>::PER16;
   constexpr int KSTEP = WK<E>::KSTEP, KT = WK<E>::KT;
   constexpr int MREP = TILE_M / 32;                         // 16-row m tiles per wave (wave tile = TILE_M/2 x 32)
@@ -130,11 +133,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
   const int halo = (KS == 3) ? a.dil : 0;
   const int x_pieces = ((KT + 2 * halo) * G::RB_N + 1023) >> 10;
 
-  f32x4 acc[KS][MREP][2];
+  f32x4 acc[KS][MREP][NREP];
 #pragma unroll
   for (int k = 0; k < KS; ++k)
 #pragma unroll
-    for (int m = 0; m < MREP; ++m) { acc[k][m][0] = f32x4{0, 0, 0, 0}; acc[k][m][1] = f32x4{0, 0, 0, 0}; }
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) acc[k][m][n] = f32x4{0, 0, 0, 0};
 
   const E* __restrict__ dyg = reinterpret_cast<const E*>(a.dy);
   const E* __restrict__ xg = reinterpret_cast<const E*>(a.x);
@@ -192,14 +197,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
         af[m] = TrOp<E, G::RB_M>::get(dys, kk * KSTEP, wave_m * (TILE_M / 2) + m * 16, lane);
 #pragma unroll
       for (int tap = 0; tap < KS; ++tap) {
-        uint4 bf[2];
+        uint4 bf[NREP];
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-          bf[n] = TrOp<E, G::RB_N>::get(xs, kk * KSTEP + tap * a.dil, wave_n * 32 + n * 16, lane);
+        for (int n = 0; n < NREP; ++n)
+          bf[n] = TrOp<E, G::RB_N>::get(xs, kk * KSTEP + tap * a.dil, wave_n * (TN / 2) + n * 16, lane);
 #pragma unroll
         for (int m = 0; m < MREP; ++m)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) acc[tap][m][n] = mma16<E>(af[m], bf[n], acc[tap][m][n]);
+          for (int n = 0; n < NREP; ++n) acc[tap][m][n] = mma16<E>(af[m], bf[n], acc[tap][m][n]);
       }
     }
   }
@@ -211,11 +216,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
 #pragma unroll
       for (int m = 0; m < MREP; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NREP; ++n)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = co0 + wave_m * (TILE_M / 2) + m * 16 + lq * 4 + r;
-            const int ci = ci0 + wave_n * 32 + n * 16 + lr;
+            const int ci = ci0 + wave_n * (TN / 2) + n * 16 + lr;
             gp[((size_t)tap * a.Cout_p + co) * a.Cin_p + ci] = acc[tap][m][n][r];
           }
     return;
@@ -228,10 +233,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
 #pragma unroll
   for (int m = 0; m < MREP; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NREP; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        ep[(wave_m * (TILE_M / 2) + m * 16 + lq * 4 + r) * EP_STRIDE + wave_n * 32 + n * 16 + lr] = acc[0][m][n][r];
+        ep[(wave_m * (TILE_M / 2) + m * 16 + lq * 4 + r) * EP_STRIDE + wave_n * (TN / 2) + n * 16 + lr] = acc[0][m][n][r];
   __syncthreads();
   E* __restrict__ og = reinterpret_cast<E*>(a.out_e);
   const E* __restrict__ sg = reinterpret_cast<const E*>(a.sub);
@@ -246,15 +251,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
       const float4 s = load4(sg + off);
       v.x -= rs * s.x; v.y -= rs * s.y; v.z -= rs * s.z; v.w -= rs * s.w;
     }
+    if (a.out_scale) { const float k = a.out_scale[0]; v.x *= k; v.y *= k; v.z *= k; v.w *= k; }
     store4(og + off, v);
   }
 }
 
-template <typename E, int TILE_M, int KS>
+template <typename E, int TILE_M, int KS, int TN>
 static int launch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
-  constexpr int lds = WGeom<E, TILE_M, KS>::LDS;
+  constexpr int lds = WGeom<E, TILE_M, KS, TN>::LDS;
   static bool attr_done = false;
-  auto kern = wgrad_gemm_kernel<E, TILE_M, KS>;
+  auto kern = wgrad_gemm_kernel<E, TILE_M, KS, TN>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             lds) != hipSuccess) {
@@ -263,17 +269,23 @@ static int launch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
     }
     attr_done = true;
   }
-  const long grid = (long)(a.Cin_p / WG_TN) * (a.Cout_p / TILE_M) * a.nseg;
+  const long grid = (long)(a.Cin_p / TN) * (a.Cout_p / TILE_M) * a.nseg;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
   return check_launch("wgrad_gemm");
 }
 
+template <typename E, int TILE_M>
+static int dispatch_wgrad_m(const sda_wgrad_args& a, hipStream_t st) {
+  if (a.KS == 3) return launch_wgrad<E, TILE_M, 3, 64>(a, st);
+  if (a.Cin_p % 128 == 0) return launch_wgrad<E, TILE_M, 1, 128>(a, st);
+  return launch_wgrad<E, TILE_M, 1, 64>(a, st);
+}
+
 template <typename E>
 static int dispatch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
-  const bool k3 = a.KS == 3;
-  if (a.Cout_p % 160 == 0) return k3 ? launch_wgrad<E, 160, 3>(a, st) : launch_wgrad<E, 160, 1>(a, st);
-  if (a.Cout_p % 128 == 0) return k3 ? launch_wgrad<E, 128, 3>(a, st) : launch_wgrad<E, 128, 1>(a, st);
-  return k3 ? launch_wgrad<E, 64, 3>(a, st) : launch_wgrad<E, 64, 1>(a, st);
+  if (a.Cout_p % 160 == 0) return dispatch_wgrad_m<E, 160>(a, st);
+  if (a.Cout_p % 128 == 0) return dispatch_wgrad_m<E, 128>(a, st);
+  return dispatch_wgrad_m<E, 64>(a, st);
 }
 
 }  // namespace sda

@@ -347,7 +347,7 @@ def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: 
     return scalars[0:1], logits, cnt, ctx
 
 
-def clip_backward(ctx: ClipCtx, dZt: torch.Tensor) -> torch.Tensor:
-    """dZ = G^T Y - diag(r) Z  (gradient of the loss share w.r.t. the local brain embeddings)."""
+def clip_backward(ctx: ClipCtx, dZt: torch.Tensor, dloss: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dZ = dloss * (G^T Y - diag(r) Z)  (gradient of the loss share w.r.t. the local brain embeddings)."""
     return ops.matmul_tn_typed(ctx.G, ctx.Yt, dZt, ctx.Zt, ctx.rscale, M_rows=ctx.Bm, N_valid=ctx.Bn,
-                               K_cols=ctx.row_elems, pitch=ctx.row_elems)
+                               K_cols=ctx.row_elems, pitch=ctx.row_elems, out_scale=dloss)

@@ -28,7 +28,7 @@ class ConvArgs(C.Structure):
 
 
 class WgradArgs(C.Structure):
-    _fields_ = [("dy", vp), ("x", vp), ("g", vp), ("out_e", vp), ("sub", vp), ("rscale", vp), ("perm", vp),
+    _fields_ = [("dy", vp), ("x", vp), ("g", vp), ("out_e", vp), ("sub", vp), ("rscale", vp), ("out_scale", vp), ("perm", vp),
                 ("seg_start", vp),
                 ("nseg", i32), ("B", i32), ("T", i32), ("Cout_p", i32), ("Cin_p", i32), ("KS", i32), ("dil", i32),
                 ("dy_pitch", i64), ("x_pitch", i64), ("out_pitch", i64), ("row0", i64), ("sample_rows", i64),

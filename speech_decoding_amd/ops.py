@@ -256,7 +256,7 @@ def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1):
     """fp32 slabs (nseg, KS, Cout_p, Cin_p) of dy^T x over the RL rows of the samples in each segment."""
     a = L.WgradArgs()
     g = torch.empty((nseg, KS, dy.shape[1], x.shape[1]), dtype=torch.float32, device=x.device)
-    a.dy, a.x, a.g, a.out_e, a.sub, a.rscale = _p(dy), _p(x), _p(g), None, None, None
+    a.dy, a.x, a.g, a.out_e, a.sub, a.rscale, a.out_scale = _p(dy), _p(x), _p(g), None, None, None, None
     a.perm, a.seg_start = _p(perm), _p(seg_start)
     a.nseg, a.B, a.T, a.Cout_p, a.Cin_p, a.KS, a.dil = nseg, B, T, dy.shape[1], x.shape[1], KS, dil
     a.dy_pitch, a.x_pitch, a.out_pitch = dy.shape[1], x.shape[1], 0
@@ -277,10 +277,10 @@ def reduce_slabs(slabs: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def matmul_tn_typed(G, Ym, out, sub, rscale, *, M_rows, N_valid, K_cols, pitch):
-    """out[j][k] = sum_i G[i][j] * Ym[i][k] - rscale[j] * sub[j][k]   (typed rows with `pitch`; loss backward)."""
+def matmul_tn_typed(G, Ym, out, sub, rscale, *, M_rows, N_valid, K_cols, pitch, out_scale=None):
+    """out[j][k] = out_scale * (sum_i G[i][j] * Ym[i][k] - rscale[j] * sub[j][k])   (typed rows with `pitch`)."""
     a = L.WgradArgs()
-    a.dy, a.x, a.g, a.out_e, a.sub, a.rscale = _p(G), _p(Ym), None, _p(out), _p(sub), _p(rscale)
+    a.dy, a.x, a.g, a.out_e, a.sub, a.rscale, a.out_scale = _p(G), _p(Ym), None, _p(out), _p(sub), _p(rscale), _p(out_scale)
     a.perm, a.seg_start = None, None
     a.nseg, a.B, a.T, a.Cout_p, a.Cin_p, a.KS, a.dil = 1, 1, M_rows, G.shape[1], K_cols, 1, 0
     a.dy_pitch, a.x_pitch, a.out_pitch = G.shape[1], pitch, pitch
