@@ -52,11 +52,28 @@ def cpu_baseline(batch: int):
             p.grad = None
         return time.perf_counter() - t0
 
-    one(4, 1)
+    one(16, 1)
     dt = one(batch, 2)
     return {"value": round(batch / dt, 3), "unit": "segments/s", "cores": threads, "kind": "port",
             "sample": f"1 training step (fwd+loss+top-k+bwd+Adam) at batch {batch}, 208ch x 360, fp32, "
                       f"{threads} torch threads, {dt:.1f} s"}
+
+
+def pmc_traffic(dtype: str, tile_co: int, ks: int):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate rocprofv3 --pmc
+    passes of this same command; tools/pmc_summary.py).  None when no summary matches."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    kernels = json.load(open(files[-1])).get("kernels", {})
+    ctype = "unsigned short" if dtype == "bf16" else "float"
+    pre = f"void sda::conv_gemm_kernel<{ctype}, {tile_co}, {ks},"
+    hits = [v for k, v in kernels.items() if k.startswith(pre)]
+    if not hits:
+        return None
+    n = sum(h["launches"] for h in hits)
+    return round(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / n)
 
 
 def main():
@@ -178,7 +195,8 @@ def main():
             n, flops, ms = summ[key]
             ach = flops / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": None,
+                               "frac": round(ach / PEAK_TFLOPS[a.dtype], 4),
+                               "traffic": pmc_traffic(a.dtype, key[2], key[3]),
                                "kernel": f"conv_gemm<{key[1]},TILE_CO={key[2]},KS={key[3]}>", "launches": n,
                                "avg_us": round(1e3 * ms / n, 2)}
             out["kernel_time_ms_per_step"] = {f"{k[0]}<{k[1]},{k[2]},{k[3]}>": round(v[2] / a.steps, 3) for k, v in summ.items()}

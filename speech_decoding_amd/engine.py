@@ -72,7 +72,7 @@ class EncoderEngine:
         self._seg_cache: Dict[tuple, tuple] = {}
         self._gen = 0
         self.reuse_workspace = True
-        self.wgrad_target_wgs = 512          # workgroups per weight-gradient launch (split over sample segments)
+        self.wgrad_target_wgs = 256          # workgroups per weight-gradient launch (split over sample segments)
 
     @property
     def world(self) -> int:
