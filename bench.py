@@ -145,8 +145,8 @@ def main():
         ranks_acc.append(sda_loss.retrieval_ranks(Y, Z))     # Classifier semantics (train.py:193-194), kept on device
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        if world > 1:
-            allreduce_gradients(params)
+        if world > 1:      # encoder gradients were all-reduced inside backward (overlapped); temp is left
+            allreduce_gradients(list(lossf.parameters()) if enc.grads_are_reduced else params)
         opt.step()
         return loss
 

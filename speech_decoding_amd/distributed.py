@@ -4,8 +4,10 @@ What shards and what is exchanged:
   * samples are sharded across ranks, weights replicated;
   * speech embeddings Y are all-gathered inside CLIPLoss so the negatives span the global batch;
   * BatchNorm partial statistics are all-reduced inside the encoder (sync_batchnorm);
-  * parameter gradients are SUM-all-reduced here in flat buckets (the loss shares already carry the
-    1/(2*B_global) normalisation, so the sum over ranks is the global-batch gradient).
+  * parameter gradients are SUM-all-reduced in flat buckets (the loss shares already carry the
+    1/(2*B_global) normalisation, so the sum over ranks is the global-batch gradient): the encoder does it
+    per layer group INSIDE backward, asynchronously on RCCL's stream (engine.overlap_grad_allreduce);
+    `allreduce_gradients` below serves whatever is left (CLIPLoss.temp) or everything when that is off.
 """
 from __future__ import annotations
 

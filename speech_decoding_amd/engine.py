@@ -68,6 +68,8 @@ class EncoderEngine:
         self.d = dims
         self.dtype = dtype
         self.group = group                # torch.distributed group for synchronised BatchNorm statistics
+        self.overlap_grad_allreduce = True   # under DP: SUM all-reduce each layer group's gradients as soon as
+                                             # they exist, on RCCL's stream, overlapped with the rest of backward
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._seg_cache: Dict[tuple, tuple] = {}
         self._gen = 0
@@ -230,6 +232,24 @@ class EncoderEngine:
         dev = dZt.device
         grads: Dict[str, torch.Tensor] = {}
         scratch = ops.reduce_scratch(max(d.Fp, 2 * d.D2p, d.F1p), dev)
+        pending = []                          # (work, names) of in-flight gradient all-reduces
+        overlap = self.world > 1 and self.overlap_grad_allreduce
+
+        def flush(names):
+            """Pack the named gradients into one flat bucket, start its SUM all-reduce asynchronously and
+            re-point the gradients at views of the bucket (no copy back)."""
+            if not overlap:
+                return
+            import torch.distributed as dist
+            flats = [torch.view_as_real(grads[n]).reshape(-1) if grads[n].is_complex() else grads[n].reshape(-1) for n in names]
+            bucket = torch.cat(flats)
+            work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            off = 0
+            for n, f in zip(names, flats):
+                v = bucket[off: off + f.numel()]
+                grads[n] = torch.view_as_complex(v.view(*grads[n].shape, 2)) if grads[n].is_complex() else v.view(grads[n].shape)
+                off += f.numel()
+            pending.append(work)
 
         def tmp(name, Cp):
             return self._rows("bw." + name, B, T, Cp, dev, "train")
@@ -258,6 +278,7 @@ class EncoderEngine:
         grads["f1w"] = wgrad(du1, bufs["x5"], 1, 0, d.F1, d.D2)
         grads["f1b"] = ops.unpack_vector(cs, d.F1)
         dx = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
+        flush(["f2w", "f2b", "f1w", "f1b"])
 
         # ---- ConvBlocks, last to first
         flip = 0
@@ -292,6 +313,8 @@ class EncoderEngine:
                 da1 = dgrad(dh, None, P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res)
             dx = da1
             flip ^= 1
+            flush([f"b{k}.c2w", f"b{k}.c2b", f"b{k}.c1w", f"b{k}.c1b", f"b{k}.bn1w", f"b{k}.bn1b",
+                   f"b{k}.c0w", f"b{k}.c0b", f"b{k}.bn0w", f"b{k}.bn0b"])
 
         # ---- SubjectBlock
         dhs = dx                                            # (rows, D1p)
@@ -306,6 +329,9 @@ class EncoderEngine:
         perm, seg, nseg = self._uniform_segments(B, (Cout_p // tile_m) * (Cin_p // 64), dev)
         dWd = ops.reduce_slabs(ops.wgrad_gemm(dh_sa, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=perm, seg_start=seg, nseg=nseg))
         grads["z"] = ops.sa_weights_backward(dWd, ctx.W_sa, ctx.mask, P["cosT"], P["sinT"], P["z"].shape[1])
+        flush(["subj_w", "sb_w", "sb_b", "z"])
+        for work in pending:
+            work.wait()                       # makes the current stream wait for RCCL's; no host sync
         return grads
 
 

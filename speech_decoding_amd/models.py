@@ -218,6 +218,13 @@ class BrainEncoder(nn.Module):
                                          self.compute_dtype, group=_dp_group() if self.sync_batchnorm else None)
         return self._engine
 
+    @property
+    def grads_are_reduced(self) -> bool:
+        """True when backward already SUM-all-reduced this module's gradients across ranks (data parallel,
+        overlapped with backward); callers then all-reduce only what lives outside the encoder (CLIPLoss.temp)."""
+        e = self.engine
+        return e.world > 1 and e.overlap_grad_allreduce
+
     def set_compute_dtype(self, dtype: torch.dtype):
         self.compute_dtype = dtype
         return self
@@ -238,13 +245,13 @@ class BrainEncoder(nn.Module):
                 centre = self._fixed_centre
             else:
                 centre = int(np.random.randint(sa.loc.shape[0]))            # models.py:81, NumPy global RNG
-                group = _dp_group()
-                if group is not None:       # "same drop centre for all samples in batch" — the batch is global
-                    import torch.distributed as dist
-                    c = torch.tensor([centre], device=X.device)
-                    dist.broadcast(c, src=0, group=group)
-                    centre = int(c.item())
             mask = sa.mask_for(centre).to(X.device, non_blocking=True)
+            group = _dp_group()
+            if group is not None and self._fixed_centre is None:
+                # "same drop centre for all samples in batch" — the batch is global: rank 0's mask wins.
+                # Broadcasting the device mask (not the index) keeps the host free of a per-step sync.
+                import torch.distributed as dist
+                dist.broadcast(mask, src=0, group=group)
         params = self._ordered_params()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # (grad mode is off inside Function.forward)
         Z = _EncoderFn.apply(self, X, subject_idxs, mask, need_grad, *params)

@@ -59,7 +59,8 @@ def _worker(rank, world, port, ret):
         Yl = Y[lo:hi].to("cuda:0")
         loss = lossf(Yl, Z)
         loss.backward()
-        allreduce_gradients(list(enc.parameters()) + list(lossf.parameters()))
+        assert enc.grads_are_reduced                                  # encoder grads: all-reduced inside backward
+        allreduce_gradients(list(lossf.parameters()))
         from speech_decoding.models import Classifier
         top = Classifier(None)(Z, Yl)                              # served from the loss's global ranks
         top_again = Classifier(None)(Z, Yl.clone())                # uncached path: gathers and ranks globally

@@ -1,0 +1,94 @@
+"""The training / evaluation driver (train.py) against the CPU oracle running the same loop on
+the same seeded synthetic dataset: per-epoch losses, retrieval accuracies, temperature and the saved
+state_dict, for both update cadences (Gwilliams2022: every batch; Brennan2018: once per epoch)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import brain_oracle as O      # noqa: E402
+
+
+def tiny_args(dataset):
+    from speech_decoding_amd import load_config
+    loc = O.synthetic_positions(12, seed=7)
+    args = load_config(overrides=[f"dataset={dataset}", "num_subjects=3", "D1=16", "D2=24", "F=32", "K=4", "batch_size=12",
+                                  "epochs=3", "num_channels=12", "preprocs.last4layers=False", "preprocs.seq_len_sec=1",
+                                  "preprocs.brain_resample_rate=40", "preprocs.baseline_len_sec=0.25", "lr=3e-4",
+                                  "synthetic_segments=40", "updates_per_epoch=2", "split_ratio=0.7"])
+    args["sensor_positions"] = loc.numpy()
+    return args, loc
+
+
+def oracle_loop(args, loc, init_state, data_cpu):
+    """train.py:166-233 restated on the oracle (CPU, fp32)."""
+    names = [k for k, v in init_state.items() if (v.is_floating_point() or v.is_complex()) and "running" not in k
+             and not k.endswith((".cos", ".sin"))]
+    P = {k: v.clone() for k, v in init_state.items()}
+    params = [P[k].clone().requires_grad_(True) for k in names]
+    temp = torch.tensor([float(args.init_temperature)], requires_grad=True)
+    stats = {k: v for k, v in P.items() if "running" in k or "num_batches" in k}
+    opt = torch.optim.Adam(params + [temp], lr=float(args.lr))
+    rows = []
+    for epoch in range(int(args.epochs)):
+        tl, t10 = [], []
+        loss = None
+        for X, Y, subj in data_cpu.train_batches(int(args.batch_size), 2):
+            Q = dict(P)
+            Q.update(dict(zip(names, params)))
+            centre = int(np.random.randint(loc.shape[0]))
+            Z = O.brain_encoder_forward(Q, X, subj, training=True, loc=loc, drop_centre=centre, stats=stats)
+            loss, _ = O.clip_loss(Y, Z, temp)
+            tl.append(loss.item())
+            t10.append(O.topk_accuracy(Z.detach(), Y)[1])
+            if args.dataset == "Gwilliams2022":
+                opt.zero_grad(); loss.backward(); opt.step()
+        if args.dataset == "Brennan2018":
+            opt.zero_grad(); loss.backward(); opt.step()
+        Q = dict(P)
+        Q.update({k: p.detach() for k, p in zip(names, params)})
+        X, Y, subj = data_cpu.test_batch()
+        with torch.no_grad():
+            Ze = O.brain_encoder_forward(Q, X, subj, training=False)
+            le, _ = O.clip_loss(Y, Ze, temp.detach())
+        rows.append(dict(train_loss=np.mean(tl), test_loss=le.item(), trainTop10acc=np.mean(t10),
+                         testTop10acc=O.topk_accuracy(Ze, Y)[1], temp=temp.item()))
+    return rows, {k: p.detach() for k, p in zip(names, params)}
+
+
+@pytest.mark.parametrize("dataset", ["Gwilliams2022", "Brennan2018"])
+def test_training_driver_matches_oracle_loop(dataset, tmp_path, monkeypatch):
+    import train as T
+    from speech_decoding.models import BrainEncoder
+    monkeypatch.chdir(tmp_path)
+    args, loc = tiny_args(dataset)
+    torch.manual_seed(0)
+    init = {k: v.clone() for k, v in BrainEncoder(args).state_dict().items()}      # same seed => same init inside run()
+    data_cpu = T.SyntheticSegments(args, 40, "cpu", seed=1234)
+    np.random.seed(0)
+    want, want_params = oracle_loop(args, loc, init, data_cpu)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    lines = []
+    hist, enc, lossf = T.run(args, log=lambda *a: lines.append(" ".join(a)))
+    assert len(hist) == 3 and len(lines) == 3 and lines[0].startswith("Ep 0/3 | ")
+    for got, ref in zip(hist, want):
+        assert abs(got["train_loss"] - ref["train_loss"]) < 2e-3 * max(1.0, ref["train_loss"])
+        assert abs(got["test_loss"] - ref["test_loss"]) < 2e-3 * max(1.0, ref["test_loss"])
+        assert got["trainTop10acc"] == pytest.approx(ref["trainTop10acc"])
+        assert got["testTop10acc"] == pytest.approx(ref["testTop10acc"])
+        assert abs(got["temp"] - ref["temp"]) < 1e-4
+    saved = torch.load(os.path.join(tmp_path, "model_last.pt"), map_location="cpu")
+    assert list(saved.keys()) == list(init.keys())                 # reference-compatible checkpoint (train.py:259)
+    moved = 0.0
+    for k, ref in want_params.items():
+        got = saved[k]
+        if ref.is_complex():
+            ref, got = torch.view_as_real(ref), torch.view_as_real(got)
+        # Adam moves every entry ~lr per step whatever its gradient's size; noise-gradient entries may differ
+        assert float((got - ref).abs().max()) < 2.5 * float(args.lr) * (6 if dataset == "Gwilliams2022" else 3) + 1e-6, k
+        moved += float((got - init[k] if not init[k].is_complex() else torch.view_as_real(saved[k]) - torch.view_as_real(init[k])).abs().max())
+    assert moved > 0
