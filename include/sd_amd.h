@@ -189,6 +189,12 @@ int sda_clip_grad(const float* logits, const float* row_lse, const float* col_ls
 int sda_clip_ranks(const float* logits, const float* diag, int32_t* cnt, int Bm, int Bn, int col0, void* stream);
 int sda_device_count(void);
 
+/* Batch collate (gwilliams2022.py:651-661): per (sample, channel) row of T fp32 samples: subtract the mean of
+ * the first baseline_len samples (preproc_utils.py:128-142), RobustScaler over time (median / inter-quartile
+ * range, sklearn semantics; preproc_utils.py:69-90), clamp to +-clamp_lim when `clamp`.  rows = B*C, T <= 1024. */
+int sda_collate_rows(const float* src, float* dst, long rows, int T, int baseline_len, float clamp_lim, int clamp,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

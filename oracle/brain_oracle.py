@@ -327,3 +327,22 @@ def train_step(P: Dict[str, Tensor], temp: Tensor, X, Y, subj, *, loc, drop_cent
     grads = {k: v.grad for k, v in leaves.items()}
     grads["temp"] = t.grad
     return loss.detach(), Z.detach(), logits.detach(), grads
+
+
+# --------------------------------------------------------------------------------------
+# batch collate: gwilliams2022.py:651-661 = preproc_utils.py:128-142 + 69-90
+# --------------------------------------------------------------------------------------
+def collate_batch(X: Tensor, baseline_len_samp: int, clamp_lim: float, clamp: bool = True) -> Tensor:
+    """Baseline-correct every (sample, channel) row by the mean of its first `baseline_len_samp` samples, then
+    RobustScaler over time per row (median, inter-quartile range with linear interpolation, zero range -> 1;
+    sklearn.preprocessing.RobustScaler defaults as called at preproc_utils.py:82), then clamp."""
+    X = X.to(torch.float32)
+    X = X - X[:, :, :baseline_len_samp].mean(dim=-1, keepdim=True)
+    x = X.numpy()
+    q25, med, q75 = np.percentile(x, [25.0, 50.0, 75.0], axis=-1)
+    scale = q75 - q25
+    scale[scale == 0.0] = 1.0
+    out = torch.from_numpy(((x - med[..., None]) / scale[..., None]).astype(np.float32))
+    if clamp:
+        out = out.clamp(-clamp_lim, clamp_lim)
+    return out

@@ -1,0 +1,41 @@
+"""GPU batch collate — drop-in for the reference's `Gwilliams2022Collator` (gwilliams2022.py:640-661):
+baseline correction + per-(sample, channel) RobustScaler + clamp, run as ONE kernel on the device instead
+of a Python loop over the batch with sklearn on DataLoader workers."""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from . import ops
+
+
+def robust_scale_clamp(X: torch.Tensor, baseline_len_samp: int, clamp_lim: float, clamp: bool = True) -> torch.Tensor:
+    """X: (B, C, T) float on the GPU -> same shape, fp32."""
+    if not X.is_cuda:
+        raise L.SdaError("collate needs device tensors (no CPU fallback)")
+    B, C, T = X.shape
+    src = X.contiguous().float()
+    out = torch.empty_like(src)
+    L.check(L.load().sda_collate_rows(src.data_ptr(), out.data_ptr(), B * C, T, int(baseline_len_samp), float(clamp_lim),
+                                      int(bool(clamp)), torch.cuda.current_stream().cuda_stream), "collate_rows")
+    return out
+
+
+class Gwilliams2022Collator(nn.Module):
+    def __init__(self, args, device="cuda"):
+        super().__init__()
+        self.brain_resample_rate = args.preprocs["brain_resample_rate"]
+        self.baseline_len_samp = int(self.brain_resample_rate * args.preprocs["baseline_len_sec"])
+        self.clamp = args.preprocs["clamp"]
+        self.clamp_lim = args.preprocs["clamp_lim"]
+        self.device = device
+
+    def forward(self, batch: List[tuple]):
+        X = torch.stack([item[0] for item in batch]).to(self.device, non_blocking=True)
+        Y = torch.stack([item[1] for item in batch])
+        subject_idx = torch.IntTensor([item[2] for item in batch])
+        X = robust_scale_clamp(X, self.baseline_len_samp, self.clamp_lim, self.clamp)
+        return X, Y, subject_idx

@@ -19,6 +19,7 @@ Fixtures:
   classifier.npz     reference `Classifier` (the B² Python loop) on a fixed (Z, Y), B = 24.
   spot_208.npz       full dims (C=208, S=27, B=8, T=360): seeded state (oracle.seeded_params, NOT
   spot_60.npz        stored), sampled Z / gradient entries, logits, loss.  Ditto C=60, S=1.
+  collate.npz        reference preproc_utils.baseline_correction_single + scaleAndClamp on a fixed batch.
 """
 import os
 import sys
@@ -34,11 +35,14 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, ROOT)
 sys.path.insert(0, REF)
 
-for name in ("termcolor", "mne", "mne_bids"):
+for name in ("termcolor", "mne", "mne_bids", "omegaconf"):
     if name not in sys.modules:
         m = types.ModuleType(name)
         if name == "termcolor":
             m.cprint = lambda *a, **k: None
+        if name == "omegaconf":             # only type names / a context manager, used by check_preprocs (not called)
+            m.DictConfig = dict
+            m.open_dict = lambda cfg: cfg
         sys.modules[name] = m
 
 import speech_decoding.models as ref_models            # noqa: E402  (the reference)
@@ -221,9 +225,28 @@ def gen_spot(C, S, tag):
     print(f"spot_{tag}: loss {float(loss):.6f} eval {float(losse):.6f} centre {centre}")
 
 
+def gen_collate():
+    """Batch collate of gwilliams2022.py:651-661, computed by the reference's own preproc_utils functions
+    (baseline_correction_single + scaleAndClamp, which call sklearn's RobustScaler)."""
+    from speech_decoding.utils import preproc_utils as PU
+    g = torch.Generator().manual_seed(21)
+    X = torch.randn(5, 7, 360, generator=g) * torch.rand(5, 7, 1, generator=g) * 4 + torch.randn(5, 7, 1, generator=g)
+    X[1, 2] = 0.25                                   # constant row: zero inter-quartile range
+    X[0, 0, 100], X[3, 4, 7] = 500.0, -300.0         # artefact spikes: exercise the clamp
+    out = PU.scaleAndClamp(PU.baseline_correction_single(X.clone(), 60), 20, True)
+    out_nc = PU.scaleAndClamp(PU.baseline_correction_single(X.clone(), 60), 20, False)
+    np.savez_compressed(os.path.join(HERE, "collate.npz"), X=X.numpy(), baseline_len=np.array(60), clamp_lim=np.array(20.0),
+                        out=out.numpy(), out_noclamp=out_nc.numpy())
+    print("collate: max |out| %.3f (unclamped %.3f)" % (out.abs().max(), out_nc.abs().max()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "collate":
+        gen_collate()
+        sys.exit(0)
     gen_e2e_small()
     gen_classifier()
     gen_spot(208, 27, "208")
     gen_spot(60, 1, "60")
+    gen_collate()
