@@ -194,6 +194,11 @@ int sda_device_count(void);
  * range, sklearn semantics; preproc_utils.py:69-90), clamp to +-clamp_lim when `clamp`.  rows = B*C, T <= 1024. */
 int sda_collate_rows(const float* src, float* dst, long rows, int T, int baseline_len, float clamp_lim, int clamp,
                      void* stream);
+/* Same, fused with the segment gather of gwilliams2022.py:129-142: sample b is the window
+ * X_session[:, onset : onset + T] of a session recording resident in HBM — win_ptr[b] points at channel 0 of the
+ * window, win_cstride[b] is that session's channel stride in elements (device arrays of length B). dst (B, C, T). */
+int sda_collate_windows(const float* const* win_ptr, const long* win_cstride, float* dst, int B, int C, int T,
+                        int baseline_len, float clamp_lim, int clamp, void* stream);
 
 #ifdef __cplusplus
 }

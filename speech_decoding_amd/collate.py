@@ -39,3 +39,32 @@ class Gwilliams2022Collator(nn.Module):
         subject_idx = torch.IntTensor([item[2] for item in batch])
         X = robust_scale_clamp(X, self.baseline_len_samp, self.clamp_lim, self.clamp)
         return X, Y, subject_idx
+
+
+class ResidentSegments:
+    """Segment gather on the GPU (gwilliams2022.py:129-142): per-session recordings (C, L_s) stay resident in HBM;
+    a batch is described by (session index, onset sample) per segment and materialised — window extraction,
+    baseline correction, robust scaling, clamp — by one kernel, replacing `__getitem__` + the collator."""
+
+    def __init__(self, sessions, seq_len_samp: int, baseline_len_samp: int, clamp_lim: float, clamp: bool = True):
+        self.sessions = [s.contiguous().float() for s in sessions]
+        if not all(s.is_cuda and s.dim() == 2 for s in self.sessions):
+            raise L.SdaError("ResidentSegments needs (C, L) device tensors")
+        self.C = self.sessions[0].shape[0]
+        self.T, self.nb, self.lim, self.clamp = int(seq_len_samp), int(baseline_len_samp), float(clamp_lim), bool(clamp)
+        self._base = torch.tensor([s.data_ptr() for s in self.sessions], dtype=torch.int64)
+        self._len = torch.tensor([s.shape[1] for s in self.sessions], dtype=torch.int64)
+
+    def batch(self, session_idx, onsets) -> torch.Tensor:
+        """session_idx, onsets: integer sequences of length B (host) -> X (B, C, T) fp32 on the device."""
+        sidx = torch.as_tensor(session_idx, dtype=torch.int64)
+        on = torch.as_tensor(onsets, dtype=torch.int64)
+        if bool(((on < 0) | (on + self.T > self._len[sidx])).any()):
+            raise IndexError("segment window leaves its session recording")
+        dev = self.sessions[0].device
+        ptrs = (self._base[sidx] + 4 * on).to(dev, non_blocking=True)
+        cstr = self._len[sidx].to(dev, non_blocking=True)
+        out = torch.empty((len(sidx), self.C, self.T), dtype=torch.float32, device=dev)
+        L.check(L.load().sda_collate_windows(ptrs.data_ptr(), cstr.data_ptr(), out.data_ptr(), len(sidx), self.C, self.T, self.nb,
+                                             self.lim, int(self.clamp), torch.cuda.current_stream().cuda_stream), "collate_windows")
+        return out

@@ -8,16 +8,21 @@
 
 namespace sda {
 
+// Row sources: either a dense (rows, T) matrix, or — segment gather, gwilliams2022.py:129-142 — per-sample
+// windows of resident session recordings: sample b = rows [b*C, (b+1)*C) read win_ptr[b] + c * win_cstride[b].
 template <int NPL>      // slots per lane; sorts 64*NPL values (T <= 64*NPL)
-__global__ __launch_bounds__(256) void collate_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                           long rows, int T, int nb, float lim, int do_clamp) {
+__global__ __launch_bounds__(256) void collate_rows_kernel(const float* __restrict__ src, const float* const* __restrict__ win_ptr,
+                                                           const long* __restrict__ win_cstride, int C,
+                                                           float* __restrict__ dst, long rows, int T, int nb, float lim,
+                                                           int do_clamp) {
   constexpr int N = 64 * NPL;
   __shared__ float sbuf[4][N];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wid;
   const bool live = row < rows;
   float* s = sbuf[wid];
-  const float* x = src + (live ? row : 0) * T;
+  const long r = live ? row : 0;
+  const float* x = win_ptr ? win_ptr[r / C] + (r % C) * win_cstride[r / C] : src + r * T;
 
   float v[NPL];
   float bsum = 0.f;
@@ -83,7 +88,19 @@ extern "C" int sda_collate_rows(const float* src, float* dst, long rows, int T, 
   if (T > 1024) { set_error("collate_rows: T = %d exceeds the 1024 samples one wavefront sorts", T); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((rows + 3) / 4);
-  if (T <= 512) hipLaunchKernelGGL(collate_rows_kernel<8>, dim3(grid), dim3(256), 0, st, src, dst, rows, T, baseline_len, clamp_lim, clamp);
-  else hipLaunchKernelGGL(collate_rows_kernel<16>, dim3(grid), dim3(256), 0, st, src, dst, rows, T, baseline_len, clamp_lim, clamp);
+  if (T <= 512) hipLaunchKernelGGL(collate_rows_kernel<8>, dim3(grid), dim3(256), 0, st, src, nullptr, nullptr, 1, dst, rows, T, baseline_len, clamp_lim, clamp);
+  else hipLaunchKernelGGL(collate_rows_kernel<16>, dim3(grid), dim3(256), 0, st, src, nullptr, nullptr, 1, dst, rows, T, baseline_len, clamp_lim, clamp);
   return check_launch("collate_rows");
+}
+
+extern "C" int sda_collate_windows(const float* const* win_ptr, const long* win_cstride, float* dst, int B, int C, int T,
+                                   int baseline_len, float clamp_lim, int clamp, void* stream) {
+  if (!win_ptr || !win_cstride || !dst || B < 1 || C < 1 || T < 2 || baseline_len < 0 || baseline_len > T) { set_error("collate_windows: bad arguments"); return -1; }
+  if (T > 1024) { set_error("collate_windows: T = %d exceeds the 1024 samples one wavefront sorts", T); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const long rows = (long)B * C;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (T <= 512) hipLaunchKernelGGL(collate_rows_kernel<8>, dim3(grid), dim3(256), 0, st, nullptr, win_ptr, win_cstride, C, dst, rows, T, baseline_len, clamp_lim, clamp);
+  else hipLaunchKernelGGL(collate_rows_kernel<16>, dim3(grid), dim3(256), 0, st, nullptr, win_ptr, win_cstride, C, dst, rows, T, baseline_len, clamp_lim, clamp);
+  return check_launch("collate_windows");
 }

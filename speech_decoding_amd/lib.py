@@ -69,6 +69,7 @@ SIGNATURES = {
     "sda_clip_logits_stats": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "sda_clip_grad": (i32, [vp, vp, vp, vp, vp, vp, f32, i32, vp, i64, vp, vp, vp, i32, i32, i32, vp]),
     "sda_collate_rows": (i32, [vp, vp, i64, i32, i32, f32, i32, vp]),
+    "sda_collate_windows": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "sda_clip_ranks": (i32, [vp, vp, vp, i32, i32, i32, vp]),
 }
 

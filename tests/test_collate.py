@@ -42,3 +42,20 @@ def test_hip_collate_matches_reference_fixture_and_oracle():
     Xc, Yc, sidx = col(batch)
     np.testing.assert_allclose(Xc.cpu().numpy(), c["out"], rtol=1e-5, atol=1e-5)
     assert Yc.shape == (5, 4, 360) and sidx.dtype == torch.int32 and sidx.tolist() == [0, 1, 2, 0, 1]
+
+
+@pytest.mark.gpu
+def test_resident_segment_gather_fused_with_collate():
+    """gwilliams2022.py:129-142 window extraction + collate in one kernel vs slicing on the host + oracle."""
+    from speech_decoding_amd.collate import ResidentSegments
+    g = torch.Generator().manual_seed(9)
+    sessions = [torch.randn(13, L, generator=g) * 2 + 0.5 for L in (5000, 7321, 4100)]
+    T, nb = 360, 60
+    rs = ResidentSegments([s.to("cuda:0") for s in sessions], T, nb, 20.0, True)
+    sidx = [2, 0, 1, 1, 0, 2, 2]
+    onsets = [0, 4640, 17, 6961, 1000, 3740, 123]
+    got = rs.batch(sidx, onsets).cpu()
+    want = O.collate_batch(torch.stack([sessions[s][:, o:o + T] for s, o in zip(sidx, onsets)]), nb, 20.0, True)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=2e-5)
+    with pytest.raises(IndexError):
+        rs.batch([0], [4700])
