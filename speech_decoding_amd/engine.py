@@ -75,6 +75,10 @@ class EncoderEngine:
         self._gen = 0
         self.reuse_workspace = True
         self.wgrad_target_wgs = 256          # workgroups per weight-gradient launch (split over sample segments)
+        # weight-gradient chains (wgrad_gemm -> reduce_slabs -> unpack) depend only on dy and a saved
+        # activation, never on each other or on the data-gradient chain: run them on a second HIP stream
+        self.wgrad_side_stream = True
+        self._side = {}
 
     @property
     def world(self) -> int:
@@ -240,6 +244,7 @@ class EncoderEngine:
             re-point the gradients at views of the bucket (no copy back)."""
             if not overlap:
                 return
+            join_side()
             import torch.distributed as dist
             flats = [torch.view_as_real(grads[n]).reshape(-1) if grads[n].is_complex() else grads[n].reshape(-1) for n in names]
             bucket = torch.cat(flats)
@@ -254,13 +259,43 @@ class EncoderEngine:
         def tmp(name, Cp):
             return self._rows("bw." + name, B, T, Cp, dev, "train")
 
+        main = torch.cuda.current_stream(dev)
+        side = None
+        if self.wgrad_side_stream:
+            side = self._side.get(str(dev))
+            if side is None:
+                side = self._side[str(dev)] = torch.cuda.Stream(device=dev)
+
+        def on_side(fn):
+            """Run `fn` (launches + allocations) on the side stream once everything queued on the main stream
+            so far is done; outputs are handed back to the main stream by join_side()."""
+            if side is None:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                out = fn()
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                t.record_stream(main)
+            return out
+
+        def join_side():
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                main.wait_event(ev)
+
         def wgrad(dy, x, KS, dil, Cout, Cin, **glu):
             Cout_p, Cin_p = dy.shape[1], x.shape[1]
             tile_m = 160 if Cout_p % 160 == 0 else (128 if Cout_p % 128 == 0 else 64)
             perm, seg, nseg = self._uniform_segments(B, (Cout_p // tile_m) * (Cin_p // 64), dev)
-            slabs = ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=perm, seg_start=seg, nseg=nseg)
-            g = ops.reduce_slabs(slabs)
-            return ops.unpack_conv_wgrad(g, 1, Cout, Cin, KS, Cout_p, Cin_p, **glu)[0]
+
+            def chain():
+                slabs = ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=perm, seg_start=seg, nseg=nseg)
+                g = ops.reduce_slabs(slabs)
+                return ops.unpack_conv_wgrad(g, 1, Cout, Cin, KS, Cout_p, Cin_p, **glu)[0]
+            return on_side(chain)
 
         def dgrad(dy, key, w_fp32, Cout_p, Cin_p, out, KS, dil, res=None, widx=None, **glu):
             wt = ops.pack_conv_weight(w_fp32, Cout_p, Cin_p, dt, mode=1, **glu)
@@ -270,14 +305,14 @@ class EncoderEngine:
         # ---- final projections
         du2 = tmp("du2", d.Fp)
         cs = ops.gelu_backward_colsum(bufs["u2"], dZt, du2, B, T, scratch)
-        grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
         grads["f2b"] = ops.unpack_vector(cs, d.F)
         dg1 = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
+        grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
         du1 = tmp("du1", d.F1p)
         cs = ops.gelu_backward_colsum(bufs["u1"], dg1, du1, B, T, scratch)
-        grads["f1w"] = wgrad(du1, bufs["x5"], 1, 0, d.F1, d.D2)
         grads["f1b"] = ops.unpack_vector(cs, d.F1)
         dx = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
+        grads["f1w"] = wgrad(du1, bufs["x5"], 1, 0, d.F1, d.D2)
         flush(["f2w", "f2b", "f1w", "f1b"])
 
         # ---- ConvBlocks, last to first
@@ -286,16 +321,18 @@ class EncoderEngine:
             cin, cin_p = (d.D1, d.D1p) if k == 0 else (d.D2, d.D2p)
             dil = block_dilations(k)
             glu = dict(glu_half=d.D2, glu_half_p=d.D2p)
-            dc2 = tmp("dc2", 2 * d.D2p)
+            dc2 = tmp(f"dc2.{k}", 2 * d.D2p)          # per-layer buffers: a side-stream wgrad may still read them
             cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
-            grads[f"b{k}.c2w"] = wgrad(dc2, bufs[f"b{k}.a1"], 3, dil[2], 2 * d.D2, d.D2, **glu)
             grads[f"b{k}.c2b"] = ops.unpack_vector(cs, 2 * d.D2, **glu)
             da1 = dgrad(dc2, None, P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2], **glu)
+            # the weight-gradient chain is queued AFTER the data-gradient conv: on the side stream it then runs
+            # beside the HBM-bound BatchNorm backward kernels that follow, not beside the MFMA-bound conv
+            grads[f"b{k}.c2w"] = wgrad(dc2, bufs[f"b{k}.a1"], 3, dil[2], 2 * d.D2, d.D2, **glu)
             x_in = bufs[f"x{k}"]
             for j in (1, 0):
                 bnp = f"b{k}.bn{j}"
                 mean, rstd = ctx.bn[bnp]
-                dh = tmp("dh", d.D2p)
+                dh = tmp(f"dh.{k}.{j}", d.D2p)
                 world = self.world
                 dgam, dbet = ops.bn_gelu_backward(da1, bufs[f"b{k}.h{j}"], mean, rstd, P[bnp + "w"], P[bnp + "b"], dh, B, T,
                                                   scratch, count=float(B) * T * world,
@@ -304,13 +341,13 @@ class EncoderEngine:
                 grads[bnp + "w"], grads[bnp + "b"] = dgam[: d.D2] / world, dbet[: d.D2] / world
                 src = bufs[f"b{k}.a0"] if j == 1 else x_in
                 ci, ci_p = (d.D2, d.D2p) if j == 1 else (cin, cin_p)
-                grads[f"b{k}.c{j}w"] = wgrad(dh, src, 3, dil[j], d.D2, ci)
                 # conv0/conv1 feed a training-mode BatchNorm, which removes any per-channel constant: the bias
                 # gradient is identically zero (the reference's autograd reports rounding noise there)
                 grads[f"b{k}.c{j}b"] = torch.zeros(d.D2, dtype=torch.float32, device=dev)
                 res = dh if (j == 1 or k > 0) else None
                 out = tmp("da", d.D2p) if j == 1 else tmp("dxB" if flip == 0 else "dxA", ci_p)
                 da1 = dgrad(dh, None, P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res)
+                grads[f"b{k}.c{j}w"] = wgrad(dh, src, 3, dil[j], d.D2, ci)
             dx = da1
             flip ^= 1
             flush([f"b{k}.c2w", f"b{k}.c2b", f"b{k}.c1w", f"b{k}.c1b", f"b{k}.bn1w", f"b{k}.bn1b",
@@ -318,8 +355,9 @@ class EncoderEngine:
 
         # ---- SubjectBlock
         dhs = dx                                            # (rows, D1p)
-        slabs = ops.wgrad_gemm(dhs, bufs["h_c"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg, nseg=d.S)
-        grads["subj_w"] = ops.unpack_conv_wgrad(slabs, d.S, d.D1, d.D1, 1, d.D1p, d.D1p)
+        grads["subj_w"] = on_side(lambda: ops.unpack_conv_wgrad(
+            ops.wgrad_gemm(dhs, bufs["h_c"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg, nseg=d.S),
+            d.S, d.D1, d.D1, 1, d.D1p, d.D1p))
         dh_c = dgrad(dhs, None, P["subj_w"], d.D1p, d.D1p, tmp("dh_c", d.D1p), 1, 0, widx=ctx.widx)
         grads["sb_w"] = wgrad(dh_c, bufs["h_sa"], 1, 0, d.D1, d.D1)
         grads["sb_b"] = ops.unpack_vector(ops.colsum(dh_c, B, T, scratch), d.D1)
@@ -330,6 +368,7 @@ class EncoderEngine:
         dWd = ops.reduce_slabs(ops.wgrad_gemm(dh_sa, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=perm, seg_start=seg, nseg=nseg))
         grads["z"] = ops.sa_weights_backward(dWd, ctx.W_sa, ctx.mask, P["cosT"], P["sinT"], P["z"].shape[1])
         flush(["subj_w", "sb_w", "sb_b", "z"])
+        join_side()
         for work in pending:
             work.wait()                       # makes the current stream wait for RCCL's; no host sync
         return grads
