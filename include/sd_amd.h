@@ -62,6 +62,20 @@ int sda_rows_sumsq(const void* x, float* out, float* scratch, int B, long row_el
  * Rows/cols beyond the source extent are zero. Cout_p/Cin_p are the padded extents of co'/ci. */
 int sda_pack_conv_weight(const float* w, void* dst, int nW, int Cout, int Cin, int KS, int Cout_p,
                          int Cin_p, int mode, int glu_half, int glu_half_p, int dtype, void* stream);
+/* All operand packs of a step in one launch.  `descs` is a DEVICE array of n descriptors: a weight pack as in
+ * sda_pack_conv_weight (dst of `dtype`), or with is_vector != 0 a bias pack as in sda_pack_vector (Cout = C,
+ * Cout_p = Cp, dst fp32).  total = number of destination elements; max_total = the largest of them. */
+typedef struct sda_pack_desc {
+  const float* src;
+  void* dst;
+  int nW, Cout, Cin, KS, Cout_p, Cin_p, mode, glu_half, glu_half_p, is_vector;
+  long total;
+} sda_pack_desc;
+int sda_pack_multi(const sda_pack_desc* descs, int n, long max_total, int dtype, void* stream);
+/* dst fp32 [Cout][Cin][KS] = ordered sum over nslabs K-split slabs [KS][Cout_p][Cin_p] (sda_wgrad_gemm output),
+ * i.e. sda_reduce_slabs + sda_unpack_conv_wgrad in one pass */
+int sda_reduce_unpack_wgrad(const float* slabs, int nslabs, float* dst, int Cout, int Cin, int KS, int Cout_p,
+                            int Cin_p, int glu_half, int glu_half_p, void* stream);
 /* fp32 vector [C] -> padded fp32 [Cp] with the same GLU remap */
 int sda_pack_vector(const float* v, float* dst, int C, int Cp, int glu_half, int glu_half_p, void* stream);
 /* inverse of mode 0 for gradients: fp32 [nW][KS][Cout_p][Cin_p] -> fp32 [nW][Cout][Cin][KS] */

@@ -123,6 +123,53 @@ __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ g, float* __r
   }
 }
 
+// All operand packs of one step in ONE launch: blockIdx.y selects the descriptor (device array).
+template <typename E>
+__global__ void pack_multi_kernel(const sda_pack_desc* __restrict__ descs) {
+  const sda_pack_desc d = descs[blockIdx.y];
+  const size_t total = (size_t)d.total;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    if (d.is_vector) {
+      const int c = glu_unmap((int)i, d.Cout, d.glu_half, d.glu_half_p);
+      reinterpret_cast<float*>(d.dst)[i] = c >= 0 ? d.src[c] : 0.f;
+      continue;
+    }
+    int co, ci, tap;
+    size_t q = i;
+    if (d.mode == 0) {
+      ci = q % d.Cin_p; q /= d.Cin_p;
+      co = glu_unmap((int)(q % d.Cout_p), d.Cout, d.glu_half, d.glu_half_p); q /= d.Cout_p;
+      tap = q % d.KS; q /= d.KS;
+    } else {
+      co = glu_unmap((int)(q % d.Cout_p), d.Cout, d.glu_half, d.glu_half_p); q /= d.Cout_p;
+      ci = q % d.Cin_p; q /= d.Cin_p;
+      tap = d.KS - 1 - (int)(q % d.KS); q /= d.KS;
+    }
+    const int n = (int)q;
+    float v = 0.f;
+    if (co >= 0 && ci < d.Cin) v = d.src[(((size_t)n * d.Cout + co) * d.Cin + ci) * d.KS + tap];
+    Elem<E>::st(reinterpret_cast<E*>(d.dst) + i, v);
+  }
+}
+
+// dst[co][ci][tap] = sum_s slabs[s][tap][co'][ci]   (ordered sum over the K-split slabs + un-packing in one pass)
+__global__ void reduce_unpack_wgrad_kernel(const float* __restrict__ slabs, int nslabs, float* __restrict__ dst, int Cout,
+                                           int Cin, int KS, int Cout_p, int Cin_p, int half, int half_p) {
+  const size_t total = (size_t)Cout * Cin * KS;
+  const size_t slab = (size_t)KS * Cout_p * Cin_p;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // thread order follows the SOURCE layout ([tap][co][ci], ci fastest) so the slab reads coalesce
+    size_t q = i;
+    const int ci = q % Cin; q /= Cin;
+    const int co = q % Cout; q /= Cout;
+    const int tap = (int)q;
+    const size_t src = ((size_t)tap * Cout_p + glu_map(co, half, half_p)) * Cin_p + ci;
+    float sum = 0.f;
+    for (int k = 0; k < nslabs; ++k) sum += slabs[(size_t)k * slab + src];
+    dst[((size_t)co * Cin + ci) * KS + tap] = sum;
+  }
+}
+
 __global__ void pack_vector_kernel(const float* __restrict__ v, float* __restrict__ dst, int C, int Cp, int half, int half_p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Cp) return;
@@ -534,6 +581,24 @@ extern "C" int sda_unpack_conv_wgrad(const float* g, float* dst, int nW, int Cou
   hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, g, dst, nW,
                      Cout, Cin, KS, Cout_p, Cin_p, glu_half, glu_half_p);
   return check_launch("unpack_conv_wgrad");
+}
+
+extern "C" int sda_pack_multi(const sda_pack_desc* descs_dev, int n, long max_total, int dtype, void* stream) {
+  if (!descs_dev || n < 1 || max_total < 1) { set_error("pack_multi: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  long gx = (max_total + 1023) / 1024;
+  if (gx > 512) gx = 512;
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_multi_kernel<E>, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, st, descs_dev));
+  return check_launch("pack_multi");
+}
+
+extern "C" int sda_reduce_unpack_wgrad(const float* slabs, int nslabs, float* dst, int Cout, int Cin, int KS, int Cout_p,
+                                       int Cin_p, int glu_half, int glu_half_p, void* stream) {
+  if (!slabs || !dst || nslabs < 1) { set_error("reduce_unpack_wgrad: bad arguments"); return -1; }
+  const size_t total = (size_t)Cout * Cin * KS;
+  hipLaunchKernelGGL(reduce_unpack_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, dst,
+                     Cout, Cin, KS, Cout_p, Cin_p, glu_half, glu_half_p);
+  return check_launch("reduce_unpack_wgrad");
 }
 
 extern "C" int sda_pack_vector(const float* v, float* dst, int C, int Cp, int glu_half, int glu_half_p, void* stream) {

@@ -60,6 +60,7 @@ class EncoderCtx:
     subj_perm: Optional[torch.Tensor] = None
     subj_seg: Optional[torch.Tensor] = None
     W_sa: Optional[torch.Tensor] = None
+    packed_T: Dict[str, torch.Tensor] = field(default_factory=dict)
 
 
 class EncoderEngine:
@@ -116,6 +117,38 @@ class EncoderEngine:
         perm, seg = self._seg_cache[key]
         return perm, seg, nseg
 
+    # ------------------------------------------------------------------ operand packing plans
+    def _plans(self, P, dev):
+        key = (str(dev), self.dtype)
+        if getattr(self, "_plan_key", None) == key:
+            return self._fwd_plan, self._bwd_plan
+        d = self.d
+        f, b = ops.PackPlan(self.dtype, dev), ops.PackPlan(self.dtype, dev)
+        glu = dict(glu_half=d.D2, glu_half_p=d.D2p)
+        f.add_weight("sb_w", P["sb_w"], d.D1p, d.D1p)
+        f.add_vector("sb_b", P["sb_b"], d.D1p)
+        f.add_weight("subj_w", P["subj_w"], d.D1p, d.D1p)
+        b.add_weight("sb_w", P["sb_w"], d.D1p, d.D1p, mode=1)
+        b.add_weight("subj_w", P["subj_w"], d.D1p, d.D1p, mode=1)
+        for k in range(5):
+            cin_p = d.D1p if k == 0 else d.D2p
+            for j in (0, 1):
+                ci_p = cin_p if j == 0 else d.D2p
+                f.add_weight(f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p)
+                f.add_vector(f"b{k}.c{j}b", P[f"b{k}.c{j}b"], d.D2p)
+                b.add_weight(f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p, mode=1)
+            f.add_weight(f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, **glu)
+            f.add_vector(f"b{k}.c2b", P[f"b{k}.c2b"], 2 * d.D2p, **glu)
+            b.add_weight(f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, mode=1, **glu)
+        f.add_weight("f1w", P["f1w"], d.F1p, d.D2p)
+        f.add_vector("f1b", P["f1b"], d.F1p)
+        f.add_weight("f2w", P["f2w"], d.Fp, d.F1p)
+        f.add_vector("f2b", P["f2b"], d.Fp)
+        b.add_weight("f1w", P["f1w"], d.F1p, d.D2p, mode=1)
+        b.add_weight("f2w", P["f2w"], d.Fp, d.F1p, mode=1)
+        self._fwd_plan, self._bwd_plan, self._plan_key = f, b, key
+        return f, b
+
     # ------------------------------------------------------------------ forward
     def forward(self, P: Dict[str, torch.Tensor], X: torch.Tensor, subject_idxs, *, training: bool,
                 mask: Optional[torch.Tensor], need_grad: bool, momentum: float = 0.1, eps: float = 1e-5) -> EncoderCtx:
@@ -150,10 +183,11 @@ class EncoderEngine:
             ctx.subj_seg = torch.from_numpy(seg).to(dev, non_blocking=True)
         ctx.mask = mask
 
-        # ---- operand packing (fp32 master weights -> compute dtype, K-contiguous, zero padded)
-        def packw(key, w, Cout_p, Cin_p, **kw):
-            pk[key] = ops.pack_conv_weight(w, Cout_p, Cin_p, dt, **kw)
-            return pk[key]
+        # ---- operand packing (fp32 master weights -> compute dtype, K-contiguous, zero padded): ONE launch
+        fwd_plan, bwd_plan = self._plans(P, dev)
+        pk.update(fwd_plan.run(P))
+        if need_grad:
+            ctx.packed_T = bwd_plan.run(P)      # [tap][ci][co] operands of the data-gradient convs
 
         # ---- SubjectBlock (models.py:111-117)
         Xt = rows("Xt", d.Cp)
@@ -163,12 +197,10 @@ class EncoderEngine:
         ctx.W_sa = W_sa
         h_sa = ops.conv_gemm(Xt, Wp, rows("h_sa", d.D1p), B=B, T=T, KS=1, dil=0, alg_dims=(d.C, d.D1))
         bufs["h_sa"] = h_sa
-        w = packw("sb_w", P["sb_w"], d.D1p, d.D1p)
-        h_c = ops.conv_gemm(h_sa, w, rows("h_c", d.D1p), B=B, T=T, KS=1, dil=0, bias=ops.pack_vector(P["sb_b"], d.D1p),
+        h_c = ops.conv_gemm(h_sa, pk["sb_w"], rows("h_c", d.D1p), B=B, T=T, KS=1, dil=0, bias=pk["sb_b"],
                             alg_dims=(d.D1, d.D1))
         bufs["h_c"] = h_c
-        w = packw("subj_w", P["subj_w"], d.D1p, d.D1p)
-        x = ops.conv_gemm(h_c, w, rows("x0", d.D1p), B=B, T=T, KS=1, dil=0, widx=ctx.widx, alg_dims=(d.D1, d.D1))
+        x = ops.conv_gemm(h_c, pk["subj_w"], rows("x0", d.D1p), B=B, T=T, KS=1, dil=0, widx=ctx.widx, alg_dims=(d.D1, d.D1))
         bufs["x0"] = x
 
         # ---- 5 ConvBlocks (models.py:152-166)
@@ -181,8 +213,7 @@ class EncoderEngine:
             for j in (0, 1):
                 alg = (d.D1 if (k == 0 and j == 0) else d.D2, d.D2)
                 pre = f"b{k}.c{j}"
-                w = packw(pre + "w", P[pre + "w"], d.D2p, cin_p if j == 0 else d.D2p)
-                bias = ops.pack_vector(P[pre + "b"], d.D2p)
+                w, bias = pk[pre + "w"], pk[pre + "b"]
                 res = x if (j == 1 or k > 0) else None
                 h = rows(f"b{k}.h{j}", d.D2p)
                 bnp = f"b{k}.bn{j}"
@@ -204,20 +235,17 @@ class EncoderEngine:
                 a = ops.bn_gelu_forward(h, rows(f"b{k}.a{j}", d.D2p), scale, shift, B, T)
                 bufs[f"b{k}.h{j}"], bufs[f"b{k}.a{j}"] = h, a
                 x = a
-            w = packw(f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, glu_half=d.D2, glu_half_p=d.D2p)
-            bias = ops.pack_vector(P[f"b{k}.c2b"], 2 * d.D2p, d.D2, d.D2p)
+            w, bias = pk[f"b{k}.c2w"], pk[f"b{k}.c2b"]
             c2 = ops.conv_gemm(x, w, rows(f"b{k}.c2", 2 * d.D2p), B=B, T=T, KS=3, dil=dil[2], bias=bias, alg_dims=(d.D2, 2 * d.D2))
             x = ops.glu_forward(c2, rows(f"x{k + 1}", d.D2p), B, T)
             bufs[f"b{k}.c2"], bufs[f"x{k + 1}"] = c2, x
 
         # ---- two 1x1 projections with GELU (models.py:194-195)
-        w = packw("f1w", P["f1w"], d.F1p, d.D2p)
         u1, g1 = rows("u1", d.F1p), rows("g1", d.F1p)
-        ops.conv_gemm(x, w, g1, B=B, T=T, KS=1, dil=0, bias=ops.pack_vector(P["f1b"], d.F1p), y_pre=u1 if need_grad else None,
+        ops.conv_gemm(x, pk["f1w"], g1, B=B, T=T, KS=1, dil=0, bias=pk["f1b"], y_pre=u1 if need_grad else None,
                       gelu=True, alg_dims=(d.D2, d.F1))
-        w = packw("f2w", P["f2w"], d.Fp, d.F1p)
         u2, Zt = rows("u2", d.Fp), self._rows("Z", B, T, d.Fp, dev, space)
-        ops.conv_gemm(g1, w, Zt, B=B, T=T, KS=1, dil=0, bias=ops.pack_vector(P["f2b"], d.Fp), y_pre=u2 if need_grad else None,
+        ops.conv_gemm(g1, pk["f2w"], Zt, B=B, T=T, KS=1, dil=0, bias=pk["f2b"], y_pre=u2 if need_grad else None,
                       gelu=True, alg_dims=(d.F1, d.F))
         bufs.update(u1=u1, g1=g1, u2=u2, Z=Zt)
         if not need_grad:
@@ -293,13 +321,11 @@ class EncoderEngine:
 
             def chain():
                 slabs = ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=perm, seg_start=seg, nseg=nseg)
-                g = ops.reduce_slabs(slabs)
-                return ops.unpack_conv_wgrad(g, 1, Cout, Cin, KS, Cout_p, Cin_p, **glu)[0]
+                return ops.reduce_unpack_wgrad(slabs, Cout, Cin, KS, **glu)
             return on_side(chain)
 
         def dgrad(dy, key, w_fp32, Cout_p, Cin_p, out, KS, dil, res=None, widx=None, **glu):
-            wt = ops.pack_conv_weight(w_fp32, Cout_p, Cin_p, dt, mode=1, **glu)
-            return ops.conv_gemm(dy, wt, out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx,
+            return ops.conv_gemm(dy, ctx.packed_T[key], out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx,
                                  alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]))
 
         # ---- final projections
@@ -316,6 +342,7 @@ class EncoderEngine:
         flush(["f2w", "f2b", "f1w", "f1b"])
 
         # ---- ConvBlocks, last to first
+        null_bias = torch.zeros((10, d.D2), dtype=torch.float32, device=dev)
         flip = 0
         for k in range(4, -1, -1):
             cin, cin_p = (d.D1, d.D1p) if k == 0 else (d.D2, d.D2p)
@@ -324,7 +351,7 @@ class EncoderEngine:
             dc2 = tmp(f"dc2.{k}", 2 * d.D2p)          # per-layer buffers: a side-stream wgrad may still read them
             cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
             grads[f"b{k}.c2b"] = ops.unpack_vector(cs, 2 * d.D2, **glu)
-            da1 = dgrad(dc2, None, P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2], **glu)
+            da1 = dgrad(dc2, f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2], **glu)
             # the weight-gradient chain is queued AFTER the data-gradient conv: on the side stream it then runs
             # beside the HBM-bound BatchNorm backward kernels that follow, not beside the MFMA-bound conv
             grads[f"b{k}.c2w"] = wgrad(dc2, bufs[f"b{k}.a1"], 3, dil[2], 2 * d.D2, d.D2, **glu)
@@ -338,15 +365,17 @@ class EncoderEngine:
                                                   scratch, count=float(B) * T * world,
                                                   allreduce=self._allreduce if world > 1 else None)
                 # under DP the sums are already global on every rank; the gradient all-reduce (SUM) follows
-                grads[bnp + "w"], grads[bnp + "b"] = dgam[: d.D2] / world, dbet[: d.D2] / world
+                if world > 1:
+                    dgam, dbet = dgam / world, dbet / world
+                grads[bnp + "w"], grads[bnp + "b"] = dgam[: d.D2], dbet[: d.D2]
                 src = bufs[f"b{k}.a0"] if j == 1 else x_in
                 ci, ci_p = (d.D2, d.D2p) if j == 1 else (cin, cin_p)
                 # conv0/conv1 feed a training-mode BatchNorm, which removes any per-channel constant: the bias
                 # gradient is identically zero (the reference's autograd reports rounding noise there)
-                grads[f"b{k}.c{j}b"] = torch.zeros(d.D2, dtype=torch.float32, device=dev)
+                grads[f"b{k}.c{j}b"] = null_bias[2 * k + j]
                 res = dh if (j == 1 or k > 0) else None
                 out = tmp("da", d.D2p) if j == 1 else tmp("dxB" if flip == 0 else "dxA", ci_p)
-                da1 = dgrad(dh, None, P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res)
+                da1 = dgrad(dh, f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res)
                 grads[f"b{k}.c{j}w"] = wgrad(dh, src, 3, dil[j], d.D2, ci)
             dx = da1
             flip ^= 1
@@ -358,10 +387,10 @@ class EncoderEngine:
         grads["subj_w"] = on_side(lambda: ops.unpack_conv_wgrad(
             ops.wgrad_gemm(dhs, bufs["h_c"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg, nseg=d.S),
             d.S, d.D1, d.D1, 1, d.D1p, d.D1p))
-        dh_c = dgrad(dhs, None, P["subj_w"], d.D1p, d.D1p, tmp("dh_c", d.D1p), 1, 0, widx=ctx.widx)
+        dh_c = dgrad(dhs, "subj_w", P["subj_w"], d.D1p, d.D1p, tmp("dh_c", d.D1p), 1, 0, widx=ctx.widx)
         grads["sb_w"] = wgrad(dh_c, bufs["h_sa"], 1, 0, d.D1, d.D1)
         grads["sb_b"] = ops.unpack_vector(ops.colsum(dh_c, B, T, scratch), d.D1)
-        dh_sa = dgrad(dh_c, None, P["sb_w"], d.D1p, d.D1p, tmp("dh_sa", d.D1p), 1, 0)
+        dh_sa = dgrad(dh_c, "sb_w", P["sb_w"], d.D1p, d.D1p, tmp("dh_sa", d.D1p), 1, 0)
         Cout_p, Cin_p = d.D1p, d.Cp
         tile_m = 160 if Cout_p % 160 == 0 else (128 if Cout_p % 128 == 0 else 64)
         perm, seg, nseg = self._uniform_segments(B, (Cout_p // tile_m) * (Cin_p // 64), dev)

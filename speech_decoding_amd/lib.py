@@ -35,6 +35,11 @@ class WgradArgs(C.Structure):
                 ("rows_limit", i64), ("dy_zero_row", i64), ("co_valid", i32), ("dtype", i32)]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("nW", i32), ("Cout", i32), ("Cin", i32), ("KS", i32), ("Cout_p", i32),
+                ("Cin_p", i32), ("mode", i32), ("glu_half", i32), ("glu_half_p", i32), ("is_vector", i32), ("total", i64)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/sd_amd.h
 SIGNATURES = {
     "sda_abi_version": (i32, []),
@@ -46,6 +51,8 @@ SIGNATURES = {
     "sda_unpack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sda_rows_sumsq": (i32, [vp, vp, vp, i32, i64, i64, i32, vp]),
     "sda_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "sda_pack_multi": (i32, [vp, i32, i64, i32, vp]),
+    "sda_reduce_unpack_wgrad": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "sda_pack_vector": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sda_unpack_conv_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "sda_unpack_vector": (i32, [vp, vp, i32, i32, i32, i32, vp]),

@@ -256,10 +256,9 @@ class BrainEncoder(nn.Module):
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # (grad mode is off inside Function.forward)
         Z = _EncoderFn.apply(self, X, subject_idxs, mask, need_grad, *params)
         if self.training:
-            for k in range(5):
-                blk = getattr(self.conv_blocks, f"conv{k}")
-                blk.batchnorm0.num_batches_tracked += 1
-                blk.batchnorm1.num_batches_tracked += 1
+            counters = [bn.num_batches_tracked for k in range(5) for bn in
+                        (getattr(self.conv_blocks, f"conv{k}").batchnorm0, getattr(self.conv_blocks, f"conv{k}").batchnorm1)]
+            torch._foreach_add_(counters, 1)
         return Z
 
 

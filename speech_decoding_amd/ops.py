@@ -80,6 +80,64 @@ def pack_conv_weight(w: torch.Tensor, Cout_p: int, Cin_p: int, dtype, mode: int 
     return out
 
 
+class PackPlan:
+    """A fixed list of operand packs (weights -> compute dtype / padded layout, biases -> padded fp32) executed by
+    ONE kernel launch.  Sources are the fp32 master parameters (stable addresses), destinations persistent
+    buffers; the descriptor table lives on the device and is rebuilt only if a source pointer changes."""
+
+    def __init__(self, dtype, device):
+        self.dtype, self.device = dtype, device
+        self.items = []          # (key, src tensor, dst tensor, desc fields)
+        self.out = {}
+        self._table = None
+        self._sig = None
+
+    def add_weight(self, key, w, Cout_p, Cin_p, mode=0, glu_half=0, glu_half_p=0):
+        if w.dim() == 3:
+            w = w.unsqueeze(0)
+        nW, Cout, Cin, KS = w.shape
+        rows, cols = (Cout_p, Cin_p) if mode == 0 else (Cin_p, Cout_p)
+        dst = torch.empty((nW, KS, rows, cols), dtype=self.dtype, device=self.device)
+        self.items.append((key, w, dst, dict(nW=nW, Cout=Cout, Cin=Cin, KS=KS, Cout_p=Cout_p, Cin_p=Cin_p, mode=mode,
+                                             glu_half=glu_half, glu_half_p=glu_half_p, is_vector=0, total=dst.numel())))
+        self.out[key] = dst
+        return dst
+
+    def add_vector(self, key, v, Cp, glu_half=0, glu_half_p=0):
+        dst = torch.empty(Cp, dtype=torch.float32, device=self.device)
+        self.items.append((key, v, dst, dict(nW=1, Cout=v.numel(), Cin=1, KS=1, Cout_p=Cp, Cin_p=1, mode=0,
+                                             glu_half=glu_half, glu_half_p=glu_half_p, is_vector=1, total=Cp)))
+        self.out[key] = dst
+        return dst
+
+    def run(self, sources):
+        """sources: {key: current fp32 tensor} (same shapes as at add time)."""
+        sig = tuple(sources[k].data_ptr() for k, *_ in self.items)
+        if sig != self._sig:
+            arr = (L.PackDesc * len(self.items))()
+            for i, (k, _, dst, f) in enumerate(self.items):
+                src = sources[k]
+                if not src.is_contiguous():
+                    raise L.SdaError(f"pack plan: parameter {k} is not contiguous")
+                arr[i].src, arr[i].dst = src.data_ptr(), dst.data_ptr()
+                for name, val in f.items():
+                    setattr(arr[i], name, val)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+            self._table = raw.to(self.device)
+            self._sig = sig
+            self._max_total = max(f["total"] for *_, f in self.items)
+        L.check(L.load().sda_pack_multi(_p(self._table), len(self.items), self._max_total, dt_code(self.dtype), _st()), "pack_multi")
+        return self.out
+
+
+def reduce_unpack_wgrad(slabs, Cout, Cin, KS, glu_half=0, glu_half_p=0) -> torch.Tensor:
+    """slabs (nseg, KS, Cout_p, Cin_p) fp32 -> parameter-layout gradient (Cout, Cin, KS) fp32."""
+    out = torch.empty((Cout, Cin, KS), dtype=torch.float32, device=slabs.device)
+    L.check(L.load().sda_reduce_unpack_wgrad(_p(slabs), slabs.shape[0], _p(out), Cout, Cin, KS, slabs.shape[2], slabs.shape[3],
+                                             glu_half, glu_half_p, _st()), "reduce_unpack_wgrad")
+    return out
+
+
 def pack_vector(v: torch.Tensor, Cp: int, glu_half: int = 0, glu_half_p: int = 0) -> torch.Tensor:
     out = torch.empty(Cp, dtype=torch.float32, device=v.device)
     L.check(L.load().sda_pack_vector(_p(v.contiguous()), _p(out), v.numel(), Cp, glu_half, glu_half_p, _st()), "pack_vector")
