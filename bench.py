@@ -123,7 +123,8 @@ def main():
     broadcast_parameters(enc)
     broadcast_parameters(lossf)
     params = list(enc.parameters()) + list(lossf.parameters())
-    opt = torch.optim.Adam(params, lr=float(cfg.lr))
+    from speech_decoding_amd.optim import FusedAdam        # same rule as torch.optim.Adam, one launch
+    opt = FusedAdam(params, lr=float(cfg.lr))
 
     # synthetic data pool resident in HBM: X ~ N(0,1) clamped ±20; Y = P·X + 0.5·eps (learnable structure)
     B = a.batch

@@ -76,6 +76,19 @@ int sda_pack_multi(const sda_pack_desc* descs, int n, long max_total, int dtype,
  * i.e. sda_reduce_slabs + sda_unpack_conv_wgrad in one pass */
 int sda_reduce_unpack_wgrad(const float* slabs, int nslabs, float* dst, int Cout, int Cin, int KS, int Cout_p,
                             int Cin_p, int glu_half, int glu_half_p, void* stream);
+/* Adam step (torch.optim.Adam defaults: no weight decay, no amsgrad; train.py:161-163) over n tensors in one
+ * launch.  descs: DEVICE array; n = number of fp32 elements (complex parameters count their real view);
+ * aligned != 0 when all four pointers are 16-byte aligned.  step = 1-based update count (bias correction). */
+typedef struct sda_adam_desc {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  long n;
+  int aligned;
+} sda_adam_desc;
+int sda_adam_multi(const sda_adam_desc* descs, int n, long max_n, float lr, float beta1, float beta2, float eps,
+                   long step, void* stream);
 /* fp32 vector [C] -> padded fp32 [Cp] with the same GLU remap */
 int sda_pack_vector(const float* v, float* dst, int C, int Cp, int glu_half, int glu_half_p, void* stream);
 /* inverse of mode 0 for gradients: fp32 [nW][KS][Cout_p][Cin_p] -> fp32 [nW][Cout][Cin][KS] */

@@ -2,6 +2,8 @@
 // backward, column sums, slab reduction.  All kernels touch VALID rows only (pad rows stay zero) and
 // move 16 bytes (fp32) / 8-16 bytes (bf16) per lane.  Reductions are two-stage and ordered, so results
 // are bitwise reproducible run to run.
+#include <math.h>
+
 #include "sd_common.h"
 
 namespace sda {
@@ -581,6 +583,51 @@ extern "C" int sda_unpack_conv_wgrad(const float* g, float* dst, int nW, int Cou
   hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, g, dst, nW,
                      Cout, Cin, KS, Cout_p, Cin_p, glu_half, glu_half_p);
   return check_launch("unpack_conv_wgrad");
+}
+
+// Adam (train.py:161-163: torch.optim.Adam defaults, no weight decay / amsgrad) over ALL parameter tensors in
+// one launch: blockIdx.y selects the tensor, complex parameters are updated through their real view.
+__global__ __launch_bounds__(256) void adam_multi_kernel(const sda_adam_desc* __restrict__ descs, float lr, float beta1,
+                                                         float beta2, float eps, float bc1, float bc2_sqrt) {
+  const sda_adam_desc d = descs[blockIdx.y];
+  const float step_size = lr / bc1;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < d.n; i += (long)gridDim.x * 1024) {
+    if (i + 4 <= d.n && d.aligned) {
+      float4 p = *reinterpret_cast<float4*>(d.param + i);
+      const float4 g = *reinterpret_cast<const float4*>(d.grad + i);
+      float4 m = *reinterpret_cast<float4*>(d.exp_avg + i), v = *reinterpret_cast<float4*>(d.exp_avg_sq + i);
+#define SDA_ADAM(f)                                                     \
+      m.f = beta1 * m.f + (1.f - beta1) * g.f;                          \
+      v.f = beta2 * v.f + (1.f - beta2) * g.f * g.f;                    \
+      p.f -= step_size * (m.f / (sqrtf(v.f) / bc2_sqrt + eps));
+      SDA_ADAM(x) SDA_ADAM(y) SDA_ADAM(z) SDA_ADAM(w)
+#undef SDA_ADAM
+      *reinterpret_cast<float4*>(d.param + i) = p;
+      *reinterpret_cast<float4*>(d.exp_avg + i) = m;
+      *reinterpret_cast<float4*>(d.exp_avg_sq + i) = v;
+    } else {
+      for (long j = i; j < min(i + 4, d.n); ++j) {
+        const float g = d.grad[j];
+        const float m = beta1 * d.exp_avg[j] + (1.f - beta1) * g;
+        const float v = beta2 * d.exp_avg_sq[j] + (1.f - beta2) * g * g;
+        d.exp_avg[j] = m;
+        d.exp_avg_sq[j] = v;
+        d.param[j] -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+      }
+    }
+  }
+}
+
+extern "C" int sda_adam_multi(const sda_adam_desc* descs_dev, int n, long max_n, float lr, float beta1, float beta2, float eps,
+                              long step, void* stream) {
+  if (!descs_dev || n < 1 || max_n < 1 || step < 1) { set_error("adam_multi: bad arguments"); return -1; }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  long gx = (max_n + 1023) / 1024;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, descs_dev, lr, beta1,
+                     beta2, eps, (float)bc1, (float)sqrt(bc2));
+  return check_launch("adam_multi");
 }
 
 extern "C" int sda_pack_multi(const sda_pack_desc* descs_dev, int n, long max_total, int dtype, void* stream) {

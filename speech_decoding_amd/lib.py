@@ -40,6 +40,10 @@ class PackDesc(C.Structure):
                 ("Cin_p", i32), ("mode", i32), ("glu_half", i32), ("glu_half_p", i32), ("is_vector", i32), ("total", i64)]
 
 
+class AdamDesc(C.Structure):
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("n", i64), ("aligned", i32)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/sd_amd.h
 SIGNATURES = {
     "sda_abi_version": (i32, []),
@@ -51,6 +55,7 @@ SIGNATURES = {
     "sda_unpack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sda_rows_sumsq": (i32, [vp, vp, vp, i32, i64, i64, i32, vp]),
     "sda_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "sda_adam_multi": (i32, [vp, i32, i64, f32, f32, f32, f32, i64, vp]),
     "sda_pack_multi": (i32, [vp, i32, i64, i32, vp]),
     "sda_reduce_unpack_wgrad": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "sda_pack_vector": (i32, [vp, vp, i32, i32, i32, i32, vp]),

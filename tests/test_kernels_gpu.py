@@ -328,3 +328,24 @@ def test_clip_loss_forward_backward_and_ranks(ops, dtype, B, F, T):
         assert torch.equal(cnt.cpu().long(), want)
     else:
         assert (cnt.cpu().long() - want).abs().max() <= 1
+
+
+def test_fused_adam_matches_torch_adam(ops):
+    """speech_decoding_amd.optim.FusedAdam vs torch.optim.Adam (train.py:161-163) over mixed shapes, a complex
+    parameter, an odd-sized tensor and a parameter without gradient; 5 steps."""
+    from speech_decoding_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(320, 270, 3), (33,), (1,), (7, 5)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).to(DEV)) for i, s in enumerate(shapes)] + \
+                 [torch.nn.Parameter(torch.randn(6, 9, dtype=torch.cfloat, generator=torch.Generator().manual_seed(9)).to(DEV)),
+                  torch.nn.Parameter(torch.zeros(4, device=DEV))]
+    pa, pb = mk(), mk()
+    oa, ob = torch.optim.Adam(pa, lr=3e-4), FusedAdam(pb, lr=3e-4)
+    for step in range(5):
+        for a, b in zip(pa[:-1], pb[:-1]):                   # the last parameter never receives a gradient
+            gr = torch.randn(a.shape, dtype=a.dtype, generator=g).to(DEV) * (10.0 ** (step - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        ra, rb = (torch.view_as_real(a), torch.view_as_real(b)) if a.is_complex() else (a, b)
+        assert float((ra - rb).abs().max()) < 2e-7 + 1e-6 * float(ra.abs().max())
