@@ -22,9 +22,9 @@ constexpr int XROWS = TILE_T + 2 * PAD;            // 160: worst-case halo
 constexpr int XS_BYTES = XROWS * ROW_B;            // 10 KB
 constexpr int EP_ROWS = 64;
 
-template <int TILE_CO> struct EpiGeom {
+template <int TILE_CO, int CH = 4> struct EpiGeom {
   static constexpr int STRIDE = TILE_CO + 4;          // floats; == 4 (mod 8): conflict-free D writes
-  static constexpr int NCH = TILE_CO / 4;             // 4-channel chunks per row
+  static constexpr int NCH = TILE_CO / CH;            // CH-channel chunks (16 bytes of E) per row
   static constexpr int RG = 256 / NCH;                // row groups
   static constexpr int ITERS = (EP_ROWS + RG - 1) / RG;
   static constexpr int EP_BYTES = EP_ROWS * STRIDE * 4;
@@ -35,7 +35,7 @@ template <int TILE_CO, int KS, int NT> constexpr int conv_stage_bytes() { return
 template <int NT, int KS> constexpr int conv_stages() { return (NT == 2 && KS == 3) ? 3 : 2; }
 template <int TILE_CO, int KS, int NT> constexpr int conv_lds_bytes() {
   constexpr int main_b = conv_stages<NT, KS>() * conv_stage_bytes<TILE_CO, KS, NT>();
-  constexpr int epi_b = NT * (EpiGeom<TILE_CO>::EP_BYTES + EpiGeom<TILE_CO>::RED_BYTES);
+  constexpr int epi_b = NT * (EpiGeom<TILE_CO, 8>::EP_BYTES + EpiGeom<TILE_CO, 8>::RED_BYTES);   // CH = 8 is the larger
   return main_b > epi_b ? main_b : epi_b;
 }
 
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
   constexpr int STAGE = conv_stage_bytes<TILE_CO, KS, NT>();
   constexpr int NW = 4 * NT;                            // waves per workgroup
   constexpr int TP = TILE_CO / 16;                      // 1 KB weight pieces per tap (16 rows x 64 B)
-  using G = EpiGeom<TILE_CO>;
+  constexpr int CH = Vec16<E>::N;                       // channels per thread in the epilogue: 16-byte global accesses
+  using G = EpiGeom<TILE_CO, CH>;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,12 +284,15 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
     }
   }
   // each tile's 4 waves run their own epilogue in a private LDS region (barriers are workgroup-wide)
-  float* ep = reinterpret_cast<float*>(smem + tsel * (G::EP_BYTES + G::RED_BYTES));
-  float* red = reinterpret_cast<float*>(smem + tsel * (G::EP_BYTES + G::RED_BYTES) + G::EP_BYTES);
+  using G8 = EpiGeom<TILE_CO, 8>;                       // region sizes as reserved by conv_lds_bytes
+  float* ep = reinterpret_cast<float*>(smem + tsel * (G8::EP_BYTES + G8::RED_BYTES));
+  float* red = reinterpret_cast<float*>(smem + tsel * (G8::EP_BYTES + G8::RED_BYTES) + G8::EP_BYTES);
   const int ltid = tid & 255;
   const int chunk = ltid % G::NCH, rg = ltid / G::NCH;
   const bool active = (rg < G::RG) && tile_ok;
-  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  float ssum[CH], ssq[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   E* __restrict__ yg = reinterpret_cast<E*>(a.y);
   E* __restrict__ ypre = reinterpret_cast<E*>(a.y_pre);
   const E* __restrict__ resg = reinterpret_cast<const E*>(a.res);
@@ -296,14 +300,15 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
 
   for (int h = 0; h < 2; ++h) {
     // residual rows of this half: issue all loads up front so their latency hides behind the LDS staging
-    float4 rv[G::ITERS];
+    float rv[G::ITERS][CH];
     if (resg && active) {
 #pragma unroll
       for (int it = 0; it < G::ITERS; ++it) {
         const int row = rg + it * G::RG;
-        rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) rv[it][j] = 0.f;
         if (row < EP_ROWS && t0 + h * EP_ROWS + row < a.T)
-          rv[it] = load4(resg + (size_t)(out_row0 + h * EP_ROWS + row) * a.Cout_p + co0 + chunk * 4);
+          Vec16<E>::load(resg + (size_t)(out_row0 + h * EP_ROWS + row) * a.Cout_p + co0 + chunk * CH, rv[it]);
       }
     }
     __syncthreads();            // main-loop LDS reads (h == 0) / previous half's reads are done
@@ -323,19 +328,27 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
         const int row = rg + it * G::RG;
         const int t = t0 + h * EP_ROWS + row;
         if (row < EP_ROWS && t < a.T) {
-          float4 v = *reinterpret_cast<const float4*>(ep + row * G::STRIDE + chunk * 4);
-          const size_t off = (size_t)(out_row0 + h * EP_ROWS + row) * a.Cout_p + co0 + chunk * 4;
-          if (resg) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
-          if (a.flags & SDA_EPI_GELU) {
-            if (ypre) store4(ypre + off, v);
-            v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+          float v[CH];
+#pragma unroll
+          for (int q4 = 0; q4 < CH / 4; ++q4) {
+            const float4 f = *reinterpret_cast<const float4*>(ep + row * G::STRIDE + chunk * CH + q4 * 4);
+            v[q4 * 4 + 0] = f.x; v[q4 * 4 + 1] = f.y; v[q4 * 4 + 2] = f.z; v[q4 * 4 + 3] = f.w;
           }
-          store4(yg + off, v);
+          const size_t off = (size_t)(out_row0 + h * EP_ROWS + row) * a.Cout_p + co0 + chunk * CH;
+          if (resg) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) v[j] += rv[it][j];
+          }
+          if (a.flags & SDA_EPI_GELU) {
+            if (ypre) Vec16<E>::store(ypre + off, v);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) v[j] = gelu_f(v[j]);
+          }
+          Vec16<E>::store(yg + off, v);
           if (a.stats) {
             // statistics of the values as stored (rounded to E), so BN normalises what it will read
-            const float4 q = round_like<E>(v);
-            ssum[0] += q.x; ssum[1] += q.y; ssum[2] += q.z; ssum[3] += q.w;
-            ssq[0] += q.x * q.x; ssq[1] += q.y * q.y; ssq[2] += q.z * q.z; ssq[3] += q.w * q.w;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { const float q = Vec16<E>::round(v[j]); ssum[j] += q; ssq[j] += q * q; }
           }
         }
       }
@@ -345,9 +358,9 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
     __syncthreads();
     if (active) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        red[(rg * 2 + 0) * TILE_CO + chunk * 4 + j] = ssum[j];
-        red[(rg * 2 + 1) * TILE_CO + chunk * 4 + j] = ssq[j];
+      for (int j = 0; j < CH; ++j) {
+        red[(rg * 2 + 0) * TILE_CO + chunk * CH + j] = ssum[j];
+        red[(rg * 2 + 1) * TILE_CO + chunk * CH + j] = ssq[j];
       }
     }
     __syncthreads();

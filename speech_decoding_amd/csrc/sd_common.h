@@ -63,6 +63,34 @@ __device__ inline void store4(uint16_t* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
+// 16 bytes of consecutive elements <-> floats: 4 fp32 or 8 bf16 (the widest global access per lane)
+template <typename E> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  __device__ static void load(const float* p, float* v) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ static void store(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+  __device__ static float round(float x) { return x; }
+};
+template <> struct Vec16<uint16_t> {
+  static constexpr int N = 8;
+  __device__ static void load(const uint16_t* p, float* v) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  __device__ static void store(uint16_t* p, const float* v) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  __device__ static float round(float x) { return bf2f(f2bf(x)); }
+};
+
 // Byte offset of 16-byte chunk `chunk` (0..7) of 128-byte LDS row `row`, XOR-swizzled so that 16
 // lanes reading the same chunk of 16 consecutive rows (the MFMA operand pattern) hit 16 distinct
 // 16-byte slots of the 256-byte bank row.
