@@ -245,20 +245,24 @@ template <typename E>
 __global__ __launch_bounds__(256) void bn_gelu_fwd_kernel(const E* __restrict__ x, E* __restrict__ y,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int B, int T, int Cp) {
-  const int nch = Cp / 4;
+  constexpr int CH = Vec16<E>::N;
+  const int nch = Cp / CH;
   const size_t total = (size_t)B * T * nch;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int ch = i % nch;
     const size_t vr = i / nch;
     const int b = vr / T, t = vr - (size_t)b * T;
-    const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
-    const float4 v = load4(x + off);
-    const float4 sc = *reinterpret_cast<const float4*>(scale + ch * 4);
-    const float4 sh = *reinterpret_cast<const float4*>(shift + ch * 4);
-    float4 o;
-    o.x = gelu_f(v.x * sc.x + sh.x); o.y = gelu_f(v.y * sc.y + sh.y);
-    o.z = gelu_f(v.z * sc.z + sh.z); o.w = gelu_f(v.w * sc.w + sh.w);
-    store4(y + off, o);
+    const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * CH;
+    float v[CH], sc[CH], sh[CH];
+    Vec16<E>::load(x + off, v);
+#pragma unroll
+    for (int q4 = 0; q4 < CH / 4; ++q4) {              // per-channel coefficients as 16-byte loads
+      *reinterpret_cast<float4*>(sc + q4 * 4) = *reinterpret_cast<const float4*>(scale + ch * CH + q4 * 4);
+      *reinterpret_cast<float4*>(sh + q4 * 4) = *reinterpret_cast<const float4*>(shift + ch * CH + q4 * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) v[j] = gelu_f(v[j] * sc[j] + sh[j]);
+    Vec16<E>::store(y + off, v);
   }
 }
 
@@ -272,37 +276,40 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int C, float* __restrict__ partial, int B, int T, int Cp) {
   extern __shared__ float red[];
-  const int nch = Cp / 4;
+  constexpr int CH = Vec16<E>::N;
+  const int nch = Cp / CH;
   const int RG = 256 / nch;
   const int ch = threadIdx.x % nch, rg = threadIdx.x / nch;
   const size_t rows = (size_t)B * T;
   const size_t per = (rows + gridDim.x - 1) / gridDim.x;
   const size_t r0 = (size_t)blockIdx.x * per, r1 = min(rows, r0 + per);
-  float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  float a0[CH], a1[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
   if (rg < RG) {
-    float mu[4], rs[4], ga[4], be[4];
+    float mu[CH], rs[CH], ga[CH], be[CH];
     if (MODE == 1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = ch * 4 + j;
+      for (int j = 0; j < CH; ++j) {
+        const int c = ch * CH + j;
         mu[j] = mean[c]; rs[j] = rstd[c];
         ga[j] = c < C ? gamma[c] : 0.f; be[j] = c < C ? beta[c] : 0.f;
       }
     }
-#pragma unroll 4
+#pragma unroll 2
     for (size_t r = r0 + rg; r < r1; r += RG) {
       const int b = r / T, t = r - (size_t)b * T;
-      const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
-      const float4 d = load4(dy + off);
-      const float dv[4] = {d.x, d.y, d.z, d.w};
+      const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * CH;
+      float dv[CH];
+      Vec16<E>::load(dy + off, dv);
       if (MODE == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a0[j] += dv[j];
+        for (int j = 0; j < CH; ++j) a0[j] += dv[j];
       } else {
-        const float4 xv4 = load4(x + off);
-        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+        float xv[CH];
+        Vec16<E>::load(x + off, xv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CH; ++j) {
           const float xh = (xv[j] - mu[j]) * rs[j];
           const float dg = dv[j] * gelu_grad_f(ga[j] * xh + be[j]);
           a0[j] += dg;
@@ -313,9 +320,9 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
   }
   if (rg < RG) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      red[(rg * 2 + 0) * Cp + ch * 4 + j] = a0[j];
-      red[(rg * 2 + 1) * Cp + ch * 4 + j] = a1[j];
+    for (int j = 0; j < CH; ++j) {
+      red[(rg * 2 + 0) * Cp + ch * CH + j] = a0[j];
+      red[(rg * 2 + 1) * Cp + ch * CH + j] = a1[j];
     }
   }
   __syncthreads();
@@ -337,48 +344,49 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
                                                          E* __restrict__ dx, float* __restrict__ partial, int B, int T,
                                                          int Ch) {
   extern __shared__ float red[];
-  const int nch = Ch / 4;
+  constexpr int CH = Vec16<E>::N;
+  const int nch = Ch / CH;
   const int RG = 256 / nch;
   const int ch = threadIdx.x % nch, rg = threadIdx.x / nch;
   const size_t rows = (size_t)B * T;
   const size_t per = (rows + gridDim.x - 1) / gridDim.x;
   const size_t r0 = (size_t)blockIdx.x * per, r1 = min(rows, r0 + per);
   const int xw = MODE == 1 ? 2 * Ch : Ch;
-  float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  float a0[CH], a1[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
   if (rg < RG) {
     for (size_t r = r0 + rg; r < r1; r += RG) {
       const int b = r / T, t = r - (size_t)b * T;
       const size_t row = (size_t)b * rows_tp(T) + PAD + t;
-      const float4 d4 = load4(dy + row * Ch + ch * 4);
-      const float4 x4 = load4(x + row * xw + ch * 4);
-      const float d[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
-      float o0[4], o1[4];
+      float d[CH], xv[CH], o0[CH], o1[CH];
+      Vec16<E>::load(dy + row * Ch + ch * CH, d);
+      Vec16<E>::load(x + row * xw + ch * CH, xv);
       if (MODE == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { o0[j] = d[j] * gelu_grad_f(xv[j]); a0[j] += o0[j]; }
-        store4(dx + row * Ch + ch * 4, make_float4(o0[0], o0[1], o0[2], o0[3]));
+        for (int j = 0; j < CH; ++j) { o0[j] = d[j] * gelu_grad_f(xv[j]); a0[j] += o0[j]; }
+        Vec16<E>::store(dx + row * Ch + ch * CH, o0);
       } else {
-        const float4 g4 = load4(x + row * xw + Ch + ch * 4);
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float g[CH];
+        Vec16<E>::load(x + row * xw + Ch + ch * CH, g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CH; ++j) {
           const float sg = sigmoid_f(g[j]);
           o0[j] = d[j] * sg;
           o1[j] = d[j] * xv[j] * sg * (1.f - sg);
+          a0[j] += o0[j];
+          a1[j] += o1[j];
         }
-        const float4 q0 = make_float4(o0[0], o0[1], o0[2], o0[3]), q1 = make_float4(o1[0], o1[1], o1[2], o1[3]);
-        store4(dx + row * xw + ch * 4, q0);
-        store4(dx + row * xw + Ch + ch * 4, q1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a0[j] += o0[j]; a1[j] += o1[j]; }
+        Vec16<E>::store(dx + row * xw + ch * CH, o0);
+        Vec16<E>::store(dx + row * xw + Ch + ch * CH, o1);
       }
     }
   }
   if (rg < RG) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      red[(rg * 2 + 0) * Ch + ch * 4 + j] = a0[j];
-      red[(rg * 2 + 1) * Ch + ch * 4 + j] = a1[j];
+    for (int j = 0; j < CH; ++j) {
+      red[(rg * 2 + 0) * Ch + ch * CH + j] = a0[j];
+      red[(rg * 2 + 1) * Ch + ch * CH + j] = a1[j];
     }
   }
   __syncthreads();
@@ -421,30 +429,30 @@ template <typename E>
 __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restrict__ dy, const E* __restrict__ x,
                                                                 const float* __restrict__ coef, E* __restrict__ dx,
                                                                 int B, int T, int Cp) {
-  const int nch = Cp / 4;
+  constexpr int CH = Vec16<E>::N;
+  const int nch = Cp / CH;
   const size_t total = (size_t)B * T * nch;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int ch = i % nch;
     const size_t vr = i / nch;
     const int b = vr / T, t = vr - (size_t)b * T;
-    const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
-    const float4 d4 = load4(dy + off), x4 = load4(x + off);
-    const float4 ga = *reinterpret_cast<const float4*>(coef + 0 * Cp + ch * 4);
-    const float4 be = *reinterpret_cast<const float4*>(coef + 1 * Cp + ch * 4);
-    const float4 mu = *reinterpret_cast<const float4*>(coef + 2 * Cp + ch * 4);
-    const float4 rs = *reinterpret_cast<const float4*>(coef + 3 * Cp + ch * 4);
-    const float4 db = *reinterpret_cast<const float4*>(coef + 4 * Cp + ch * 4);
-    const float4 dg = *reinterpret_cast<const float4*>(coef + 5 * Cp + ch * 4);
-    float4 o;
-#define SDA_BN_BWD(f)                                          \
-    {                                                          \
-      const float xh = (x4.f - mu.f) * rs.f;                   \
-      const float g = d4.f * gelu_grad_f(ga.f * xh + be.f);    \
-      o.f = ga.f * rs.f * (g - db.f - xh * dg.f);              \
+    const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * CH;
+    float d[CH], xv[CH], o[CH], cf[6][CH];
+    Vec16<E>::load(dy + off, d);
+    Vec16<E>::load(x + off, xv);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int q4 = 0; q4 < CH / 4; ++q4)                // per-channel coefficients as 16-byte loads
+        *reinterpret_cast<float4*>(&cf[k][q4 * 4]) = *reinterpret_cast<const float4*>(coef + (size_t)k * Cp + ch * CH + q4 * 4);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const float ga = cf[0][j], be = cf[1][j], mu = cf[2][j], rs = cf[3][j];
+      const float xh = (xv[j] - mu) * rs;
+      const float g = d[j] * gelu_grad_f(ga * xh + be);
+      o[j] = ga * rs * (g - cf[4][j] - xh * cf[5][j]);
     }
-    SDA_BN_BWD(x) SDA_BN_BWD(y) SDA_BN_BWD(z) SDA_BN_BWD(w)
-#undef SDA_BN_BWD
-    store4(dx + off, o);
+    Vec16<E>::store(dx + off, o);
   }
 }
 
@@ -453,16 +461,20 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restr
 // ------------------------------------------------------------------------------------------------
 template <typename E>
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const E* __restrict__ x, E* __restrict__ y, int B, int T, int Ch) {
-  const int nch = Ch / 4;
+  constexpr int CH = Vec16<E>::N;
+  const int nch = Ch / CH;
   const size_t total = (size_t)B * T * nch;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int ch = i % nch;
     const size_t vr = i / nch;
     const int b = vr / T, t = vr - (size_t)b * T;
     const size_t row = (size_t)b * rows_tp(T) + PAD + t;
-    const float4 a = load4(x + row * 2 * Ch + ch * 4), g = load4(x + row * 2 * Ch + Ch + ch * 4);
-    store4(y + row * Ch + ch * 4, make_float4(a.x * sigmoid_f(g.x), a.y * sigmoid_f(g.y), a.z * sigmoid_f(g.z),
-                                              a.w * sigmoid_f(g.w)));
+    float a[CH], g[CH];
+    Vec16<E>::load(x + row * 2 * Ch + ch * CH, a);
+    Vec16<E>::load(x + row * 2 * Ch + Ch + ch * CH, g);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) a[j] *= sigmoid_f(g[j]);
+    Vec16<E>::store(y + row * Ch + ch * CH, a);
   }
 }
 
@@ -692,7 +704,7 @@ extern "C" int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const 
   }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const int RG = 256 / (Cp / 4);
+  const int RG = 256 / (Cp / (dtype == SDA_BF16 ? 8 : 4));
   const size_t lds = (size_t)RG * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((col_reduce_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)dy,
                                          (const E*)x, mean, rstd, gamma, beta, C, partial, B, T, Cp));
@@ -721,7 +733,7 @@ extern "C" int sda_colsum(const void* x, float* out, float* scratch, int B, int 
   if (!x || !out || !scratch || Cp % 64 || Cp > 1024) { set_error("colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const int RG = 256 / (Cp / 4);
+  const int RG = 256 / (Cp / (dtype == SDA_BF16 ? 8 : 4));
   const size_t lds = (size_t)RG * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((col_reduce_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)x,
                                          (const E*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, B, T, Cp));
@@ -760,7 +772,7 @@ extern "C" int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, 
   if (!x || !dy || !dx || !colsum || !scratch || Ch % 64 || Ch > 1024) { set_error("glu_backward_colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const size_t lds = (size_t)(256 / (Ch / 4)) * 2 * Ch * sizeof(float);
+  const size_t lds = (size_t)(256 / (Ch / (dtype == SDA_BF16 ? 8 : 4))) * 2 * Ch * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)x,
                                          (const E*)dy, (E*)dx, scratch, B, T, Ch));
   hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
@@ -772,7 +784,7 @@ extern "C" int sda_gelu_backward_colsum(const void* u, const void* dz, void* du,
   if (!u || !dz || !du || !colsum || !scratch || Cp % 64 || Cp > 1024) { set_error("gelu_backward_colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const size_t lds = (size_t)(256 / (Cp / 4)) * 2 * Cp * sizeof(float);
+  const size_t lds = (size_t)(256 / (Cp / (dtype == SDA_BF16 ? 8 : 4))) * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)u,
                                          (const E*)dz, (E*)du, scratch, B, T, Cp));
   hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, (float*)nullptr, Cp);
