@@ -48,9 +48,25 @@ def _rows_base(t: torch.Tensor, B: int, Cc: int, T: int, dtype):
     return t.detach().as_strided((rows, Cp), (Cp, 1), 0)
 
 
-def as_rows(t: torch.Tensor, B: int, Cc: int, T: int, dtype, name: str) -> torch.Tensor:
+_pack_ring = {}           # (slot key, B, C, T, dtype, device) -> [buffers], next index
+
+
+def _ring_rows(key, B, Cc, T, dtype, device, depth=2):
+    """Persistent RL buffers for packed inputs (no per-call 200 MB allocation + memset).  `depth` buffers
+    rotate so that the buffer a pending backward still needs survives one further forward (e.g. an eval
+    pass between forward and backward)."""
+    k = (key, B, Cc, T, dtype, str(device))
+    ring = _pack_ring.get(k)
+    if ring is None:
+        ring = _pack_ring[k] = [[ops.new_rows(B, T, L.pad_channels(Cc), dtype, device) for _ in range(depth)], 0]
+    buf = ring[0][ring[1] % depth]
+    ring[1] += 1
+    return buf
+
+
+def as_rows(t: torch.Tensor, B: int, Cc: int, T: int, dtype, name: str, ring_key=None) -> torch.Tensor:
     """Return the RL buffer behind `t` (zero copy when `t` is a rows_view made by this package), else
-    pack a plain (B, C, T) tensor into a fresh RL buffer."""
+    pack a plain (B, C, T) tensor into an RL buffer (a rotating persistent one when `ring_key` is given)."""
     if tuple(t.shape) != (B, Cc, T):
         raise ValueError(f"{name}: expected shape {(B, Cc, T)}, got {tuple(t.shape)}")
     base = _rows_base(t, B, Cc, T, dtype)
@@ -58,7 +74,10 @@ def as_rows(t: torch.Tensor, B: int, Cc: int, T: int, dtype, name: str) -> torch
         return base
     if not t.is_cuda:
         raise L.SdaError(f"{name} must live on the MI355X device (there is no CPU path)")
-    buf = ops.new_rows(B, T, L.pad_channels(Cc), dtype, t.device)
+    if ring_key is not None:
+        buf = _ring_rows(ring_key, B, Cc, T, dtype, t.device)       # pack_rows rewrites every valid row
+    else:
+        buf = ops.new_rows(B, T, L.pad_channels(Cc), dtype, t.device)
     ops.pack_rows(t.detach().float().contiguous(), buf)
     return buf
 
@@ -90,7 +109,7 @@ class _ClipFn(torch.autograd.Function):
         B, F, T = Z.shape
         dtype = Z.dtype if Z.dtype in (torch.float32, torch.bfloat16) else torch.float32
         Zt = as_rows(Z, B, F, T, dtype, "y (brain embeddings)")
-        Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)")
+        Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y")
         group = _dist_group() if module.global_negatives else None
         Yt, Bm, col0, Bg = gather_speech_rows(Yt_local, B, T, group)
         loss, logits, cnt, cctx = E.clip_forward(Yt, Zt, temp.detach(), Bm=Bm, Bn=B, T=T, col0=col0,
