@@ -215,6 +215,9 @@ int sda_clip_grad(const float* logits, const float* row_lse, const float* col_ls
 /* cnt[i] = #{local j : logits[i][j] beats diag[i]} (ties: lower global index wins) — Classifier ranks */
 int sda_clip_ranks(const float* logits, const float* diag, int32_t* cnt, int Bm, int Bn, int col0, void* stream);
 int sda_device_count(void);
+/* Asynchronous upload of a small host table (nwords 32-bit words) carried in kernel arguments: no memcpy, no
+ * host<->stream synchronisation. The host buffer is read before the call returns. */
+int sda_upload_words(void* dst, const void* src_host, long nwords, void* stream);
 
 /* Batch collate (gwilliams2022.py:651-661): per (sample, channel) row of T fp32 samples: subtract the mean of
  * the first baseline_len samples (preproc_utils.py:128-142), RobustScaler over time (median / inter-quartile

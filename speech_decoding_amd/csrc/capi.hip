@@ -1,6 +1,7 @@
 // C ABI plumbing: error reporting, layout helpers.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "sd_common.h"
 
@@ -34,4 +35,28 @@ extern "C" int sda_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// Small host -> device tables travel INSIDE the kernel-argument block of a tiny kernel (up to 3.75 KB per
+// launch) instead of through hipMemcpyAsync: a copy from pageable memory makes the host wait until the stream
+// reaches it (a per-step synchronisation), a kernarg payload is captured at launch time and is fully asynchronous.
+namespace sda {
+constexpr int UPLOAD_WORDS = 960;
+struct UploadPayload { uint32_t w[UPLOAD_WORDS]; };
+__global__ void upload_words_kernel(uint32_t* __restrict__ dst, const UploadPayload p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = p.w[i];
+}
+}  // namespace sda
+
+extern "C" int sda_upload_words(void* dst, const void* src_host, long nwords, void* stream) {
+  if (!dst || !src_host || nwords < 1) { sda::set_error("upload_words: bad arguments"); return -1; }
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(src_host);
+  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+  for (long off = 0; off < nwords; off += sda::UPLOAD_WORDS) {
+    sda::UploadPayload p;
+    const int n = (int)((nwords - off) < sda::UPLOAD_WORDS ? (nwords - off) : sda::UPLOAD_WORDS);
+    memcpy(p.w, src + off, (size_t)n * 4);
+    hipLaunchKernelGGL(sda::upload_words_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d + off, p, n);
+  }
+  return sda::check_launch("upload_words");
 }

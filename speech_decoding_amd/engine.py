@@ -175,12 +175,13 @@ class EncoderEngine:
             raise ValueError("subject_idxs must have shape (B,)")
         if (sidx < 0).any() or (sidx >= d.S).any():
             raise IndexError("subject index out of range")                # ModuleList semantics, models.py:115
-        ctx.widx = torch.from_numpy(sidx.astype(np.int32)).to(dev, non_blocking=True)
+        up = ops.UPLOADER.upload                # pinned staging: no implicit host<->stream synchronisation
+        ctx.widx = up(("widx", space), sidx.astype(np.int32), dev)
         if need_grad:
             order = np.argsort(sidx, kind="stable").astype(np.int32)
             seg = np.searchsorted(sidx[order], np.arange(d.S + 1)).astype(np.int32)
-            ctx.subj_perm = torch.from_numpy(order).to(dev, non_blocking=True)
-            ctx.subj_seg = torch.from_numpy(seg).to(dev, non_blocking=True)
+            ctx.subj_perm = up("subj_perm", order, dev)
+            ctx.subj_seg = up("subj_seg", seg, dev)
         ctx.mask = mask
 
         # ---- operand packing (fp32 master weights -> compute dtype, K-contiguous, zero padded): ONE launch

@@ -51,6 +51,7 @@ SIGNATURES = {
     "sda_rows_alloc": (i64, [i32, i32]),
     "sda_pad_channels": (i32, [i32]),
     "sda_device_count": (i32, []),
+    "sda_upload_words": (i32, [vp, vp, i64, vp]),
     "sda_pack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sda_unpack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sda_rows_sumsq": (i32, [vp, vp, vp, i32, i64, i64, i32, vp]),

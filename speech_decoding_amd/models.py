@@ -71,6 +71,14 @@ class SpatialAttention(nn.Module):
         centre = int(np.random.randint(self.loc.shape[0]))
         return self.mask_for(centre)
 
+    def device_masks(self, device) -> torch.Tensor:
+        """All C possible dropout masks (row = centre sensor), built once and kept on the device."""
+        m = getattr(self, "_masks", None)
+        if m is None or m.device != torch.device(device):
+            dist = (self.loc[:, None, :] - self.loc[None, :, :]).norm(dim=-1)
+            m = self._masks = torch.where(dist < self.d_drop, 0.0, 1.0).to(torch.float32).to(device)
+        return m
+
     def mask_for(self, centre: int) -> torch.Tensor:
         dist = (self.loc - self.loc[centre]).norm(dim=-1)
         return torch.where(dist < self.d_drop, 0.0, 1.0).to(torch.float32)
@@ -245,9 +253,10 @@ class BrainEncoder(nn.Module):
                 centre = self._fixed_centre
             else:
                 centre = int(np.random.randint(sa.loc.shape[0]))            # models.py:81, NumPy global RNG
-            mask = sa.mask_for(centre).to(X.device, non_blocking=True)
+            mask = sa.device_masks(X.device)[centre]            # (C, C) table resident on the device: no upload
             group = _dp_group()
             if group is not None and self._fixed_centre is None:
+                mask = mask.clone()             # the cached table must not be overwritten by the broadcast
                 # "same drop centre for all samples in batch" — the batch is global: rank 0's mask wins.
                 # Broadcasting the device mask (not the index) keeps the host free of a per-step sync.
                 import torch.distributed as dist
