@@ -141,6 +141,7 @@ def main():
 
     def step(i):
         X, Y, subj = pool[i % len(pool)]
+        lossf.prefetch(Y, enc.compute_dtype)                 # pack Y (+ all-gather it under DP) while the encoder runs
         Z = enc(X, subj)
         loss = lossf(Y, Z)
         ranks_acc.append(sda_loss.retrieval_ranks(Y, Z))     # Classifier semantics (train.py:193-194), kept on device

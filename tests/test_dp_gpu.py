@@ -55,8 +55,9 @@ def _worker(rank, world, port, ret):
         lo, hi = shard_range(Bg, rank, world)
         enc, lossf = build("fp32", P)
         enc.set_drop_centre(4)
-        Z = enc(X[lo:hi].to("cuda:0"), subj[lo:hi])
         Yl = Y[lo:hi].to("cuda:0")
+        lossf.prefetch(Yl, torch.float32)                          # async all-gather of Y overlapping the encoder
+        Z = enc(X[lo:hi].to("cuda:0"), subj[lo:hi])
         loss = lossf(Yl, Z)
         loss.backward()
         assert enc.grads_are_reduced                                  # encoder grads: all-reduced inside backward

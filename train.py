@@ -122,6 +122,7 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
             if world > 1:
                 lo, hi = shard_range(X.shape[0], rank, world)
                 X, Y, subject_idxs = X[lo:hi], Y[lo:hi], subject_idxs[lo:hi]
+            loss_func.prefetch(Y, brain_encoder.compute_dtype)     # Y-side work (+ DP all-gather) overlaps the encoder
             Z = brain_encoder(X, subject_idxs)
             loss = loss_func(Y, Z)
             with torch.no_grad():
