@@ -191,7 +191,9 @@ int sda_reduce_slabs(const float* src, float* dst, int nslabs, long n, void* str
  * a = Re(z) cos + Im(z) sin; W = softmax_c(a); Wd = W * mask.  z is complex64 interleaved (re, im).
  * Outputs: W fp32 [D1][C] (saved for backward) and the packed operand Wp `dtype` [D1p][Cp]. */
 int sda_sa_weights_forward(const float* z, const float* cos_t, const float* sin_t, const float* mask,
-                           float* W, void* Wp, int D1, int K2, int C, int D1p, int Cp, int dtype, void* stream);
+                           float* W, void* Wp, float* scratch /* sda_sa_scratch_floats(D1, K2, C) */, int D1, int K2,
+                           int C, int D1p, int Cp, int dtype, void* stream);
+int sda_sa_scratch_floats(int D1, int K2, int C);
 /* dWd fp32 [D1p][Cp] (from sda_wgrad_gemm) -> dz complex64 interleaved [D1][K2].
  * cosT/sinT are the transposed tables [C][K2] (constant buffers, transposed once by the host). */
 int sda_sa_weights_backward(const float* dWd, const float* W, const float* mask, const float* cosT,

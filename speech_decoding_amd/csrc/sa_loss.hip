@@ -20,47 +20,68 @@ __device__ inline float block_max(float v, float* sh) {
   return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
 
-// One block per output row o.  a[o][c] = sum_m Re z[o][m] cos[m][c] + Im z[o][m] sin[m][c]; softmax over c.
+// SpatialAttention weights, forward.  a[o][c] = sum_m Re z[o][m] cos[m][c] + Im z[o][m] sin[m][c].
+// Stage 1: block (row group of SA_R rows, m-chunk of SA_MC) accumulates partial sums for all sensors; every
+// table element it loads feeds SA_R rows (the tables are the traffic: 2 x K2 x C floats).  Stage 2: one block
+// per row sums the m-chunk partials in fixed order, takes the softmax over sensors, applies the dropout mask
+// and writes the packed MFMA operand.
+constexpr int SA_R = 8;
+constexpr int SA_MC = 128;
+
+__global__ __launch_bounds__(256) void sa_fwd_partial_kernel(const float* __restrict__ z, const float* __restrict__ cos_t,
+                                                             const float* __restrict__ sin_t, float* __restrict__ part,
+                                                             int D1, int K2, int C) {
+  __shared__ float zs[SA_R][SA_MC][2];
+  const int o0 = blockIdx.x * SA_R, m0 = blockIdx.y * SA_MC, tid = threadIdx.x;
+  for (int i = tid; i < SA_R * SA_MC; i += 256) {
+    const int r = i / SA_MC, m = i - r * SA_MC;
+    const bool ok = (o0 + r < D1) && (m0 + m < K2);
+    zs[r][m][0] = ok ? z[((size_t)(o0 + r) * K2 + m0 + m) * 2 + 0] : 0.f;
+    zs[r][m][1] = ok ? z[((size_t)(o0 + r) * K2 + m0 + m) * 2 + 1] : 0.f;
+  }
+  __syncthreads();
+  const int mm = min(SA_MC, K2 - m0);
+  for (int c = tid; c < C; c += 256) {
+    float acc[SA_R];
+#pragma unroll
+    for (int r = 0; r < SA_R; ++r) acc[r] = 0.f;
+    for (int m = 0; m < mm; ++m) {
+      const float cv = cos_t[(size_t)(m0 + m) * C + c], sv = sin_t[(size_t)(m0 + m) * C + c];
+#pragma unroll
+      for (int r = 0; r < SA_R; ++r) acc[r] += zs[r][m][0] * cv + zs[r][m][1] * sv;
+    }
+#pragma unroll
+    for (int r = 0; r < SA_R; ++r)
+      if (o0 + r < D1) part[((size_t)blockIdx.y * D1 + o0 + r) * C + c] = acc[r];
+  }
+}
+
 template <typename E>
-__global__ __launch_bounds__(256) void sa_weights_fwd_kernel(const float* __restrict__ z, const float* __restrict__ cos_t,
-                                                             const float* __restrict__ sin_t, const float* __restrict__ mask,
-                                                             float* __restrict__ W, E* __restrict__ Wp, int D1, int K2,
-                                                             int C, int Cp) {
+__global__ __launch_bounds__(256) void sa_fwd_final_kernel(const float* __restrict__ part, int nchunk,
+                                                           const float* __restrict__ mask, float* __restrict__ W,
+                                                           E* __restrict__ Wp, int D1, int C, int Cp) {
   __shared__ float sh[4];
-  __shared__ float zs[2][256];
   const int o = blockIdx.x, tid = threadIdx.x;
   if (o >= D1) {                                   // padded output rows of the packed operand
     for (int c = tid; c < Cp; c += 256) Elem<E>::st(Wp + (size_t)o * Cp + c, 0.f);
     return;
   }
   constexpr int MAXC = 2;                          // up to 512 sensors
-  float acc[MAXC] = {0.f, 0.f};
-  for (int m0 = 0; m0 < K2; m0 += 256) {
-    __syncthreads();
-    if (m0 + tid < K2) {
-      zs[0][tid] = z[((size_t)o * K2 + m0 + tid) * 2 + 0];
-      zs[1][tid] = z[((size_t)o * K2 + m0 + tid) * 2 + 1];
-    }
-    __syncthreads();
-    const int mm = min(256, K2 - m0);
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      const int c = tid + k * 256;
-      if (c < C) {
-        float s = acc[k];
-        for (int m = 0; m < mm; ++m)
-          s += zs[0][m] * cos_t[(size_t)(m0 + m) * C + c] + zs[1][m] * sin_t[(size_t)(m0 + m) * C + c];
-        acc[k] = s;
-      }
-    }
-  }
+  float a[MAXC];
   float mx = -INFINITY;
 #pragma unroll
-  for (int k = 0; k < MAXC; ++k) if (tid + k * 256 < C) mx = fmaxf(mx, acc[k]);
+  for (int k = 0; k < MAXC; ++k) {
+    const int c = tid + k * 256;
+    a[k] = 0.f;
+    if (c < C) {
+      for (int j = 0; j < nchunk; ++j) a[k] += part[((size_t)j * D1 + o) * C + c];
+      mx = fmaxf(mx, a[k]);
+    }
+  }
   mx = block_max(mx, sh);
   float ex[MAXC], sum = 0.f;
 #pragma unroll
-  for (int k = 0; k < MAXC; ++k) { ex[k] = (tid + k * 256 < C) ? expf(acc[k] - mx) : 0.f; sum += ex[k]; }
+  for (int k = 0; k < MAXC; ++k) { ex[k] = (tid + k * 256 < C) ? expf(a[k] - mx) : 0.f; sum += ex[k]; }
   sum = block_sum(sum, sh);
   const float inv = 1.f / sum;
 #pragma unroll
@@ -75,32 +96,45 @@ __global__ __launch_bounds__(256) void sa_weights_fwd_kernel(const float* __rest
   for (int c = C + tid; c < Cp; c += 256) Elem<E>::st(Wp + (size_t)o * Cp + c, 0.f);
 }
 
-// One block per row o: softmax backward on the row, then dz[o][m] = sum_c da[c] * (cosT | sinT)[c][m].
+// Backward: block (row group of SA_R rows, 256 Fourier modes).  Prologue: softmax backward of its rows into
+// LDS (da[r][c] = W (dW - <dW, W>)); then dz[o][m] = sum_c da[o][c] * (cosT | sinT)[c][m], every transposed-table
+// element feeding SA_R rows.
 __global__ __launch_bounds__(256) void sa_weights_bwd_kernel(const float* __restrict__ dWd, const float* __restrict__ W,
                                                              const float* __restrict__ mask, const float* __restrict__ cosT,
                                                              const float* __restrict__ sinT, float* __restrict__ dz, int D1,
                                                              int K2, int C, int Cp) {
   __shared__ float sh[4];
-  __shared__ float da[512];
-  const int o = blockIdx.x, tid = threadIdx.x;
-  float dot = 0.f;
-  for (int c = tid; c < C; c += 256) {
-    const float dw = dWd[(size_t)o * Cp + c] * (mask ? mask[c] : 1.f);
-    da[c] = dw;
-    dot += dw * W[(size_t)o * C + c];
-  }
-  dot = block_sum(dot, sh);
-  for (int c = tid; c < C; c += 256) da[c] = W[(size_t)o * C + c] * (da[c] - dot);
-  __syncthreads();
-  for (int m = tid; m < K2; m += 256) {
-    float sr = 0.f, si = 0.f;
-    for (int c = 0; c < C; ++c) {
-      sr += da[c] * cosT[(size_t)c * K2 + m];
-      si += da[c] * sinT[(size_t)c * K2 + m];
+  __shared__ float da[SA_R][512];
+  const int o0 = blockIdx.x * SA_R, m = blockIdx.y * 256 + threadIdx.x, tid = threadIdx.x;
+  for (int r = 0; r < SA_R; ++r) {
+    const int o = o0 + r;
+    float dot = 0.f;
+    if (o < D1) {
+      for (int c = tid; c < C; c += 256) {
+        const float dw = dWd[(size_t)o * Cp + c] * (mask ? mask[c] : 1.f);
+        da[r][c] = dw;
+        dot += dw * W[(size_t)o * C + c];
+      }
     }
-    dz[((size_t)o * K2 + m) * 2 + 0] = sr;
-    dz[((size_t)o * K2 + m) * 2 + 1] = si;
+    dot = block_sum(dot, sh);
+    for (int c = tid; c < C; c += 256) da[r][c] = (o < D1) ? W[(size_t)o * C + c] * (da[r][c] - dot) : 0.f;
   }
+  __syncthreads();
+  if (m >= K2) return;
+  float sr[SA_R], si[SA_R];
+#pragma unroll
+  for (int r = 0; r < SA_R; ++r) { sr[r] = 0.f; si[r] = 0.f; }
+  for (int c = 0; c < C; ++c) {
+    const float cv = cosT[(size_t)c * K2 + m], sv = sinT[(size_t)c * K2 + m];
+#pragma unroll
+    for (int r = 0; r < SA_R; ++r) { sr[r] += da[r][c] * cv; si[r] += da[r][c] * sv; }
+  }
+#pragma unroll
+  for (int r = 0; r < SA_R; ++r)
+    if (o0 + r < D1) {
+      dz[((size_t)(o0 + r) * K2 + m) * 2 + 0] = sr[r];
+      dz[((size_t)(o0 + r) * K2 + m) * 2 + 1] = si[r];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- loss tail
@@ -200,14 +234,18 @@ __global__ __launch_bounds__(256) void clip_ranks_kernel(const float* __restrict
 
 using namespace sda;
 
+extern "C" int sda_sa_scratch_floats(int D1, int K2, int C) { return ((K2 + SA_MC - 1) / SA_MC) * D1 * C; }
+
 extern "C" int sda_sa_weights_forward(const float* z, const float* cos_t, const float* sin_t, const float* mask, float* W,
-                                      void* Wp, int D1, int K2, int C, int D1p, int Cp, int dtype, void* stream) {
-  if (!z || !cos_t || !sin_t || !W || !Wp || C > 512 || C > Cp || D1 > D1p) { set_error("sa_weights_forward: bad arguments (C <= 512)"); return -1; }
+                                      void* Wp, float* scratch, int D1, int K2, int C, int D1p, int Cp, int dtype, void* stream) {
+  if (!z || !cos_t || !sin_t || !W || !Wp || !scratch || C > 512 || C > Cp || D1 > D1p) { set_error("sa_weights_forward: bad arguments (C <= 512)"); return -1; }
   hipStream_t st = (hipStream_t)stream;
+  const int nchunk = (K2 + SA_MC - 1) / SA_MC;
+  hipLaunchKernelGGL(sa_fwd_partial_kernel, dim3((D1 + SA_R - 1) / SA_R, nchunk), dim3(256), 0, st, z, cos_t, sin_t, scratch, D1, K2, C);
   if (dtype == SDA_F32)
-    hipLaunchKernelGGL(sa_weights_fwd_kernel<float>, dim3(D1p), dim3(256), 0, st, z, cos_t, sin_t, mask, W, (float*)Wp, D1, K2, C, Cp);
+    hipLaunchKernelGGL(sa_fwd_final_kernel<float>, dim3(D1p), dim3(256), 0, st, scratch, nchunk, mask, W, (float*)Wp, D1, C, Cp);
   else if (dtype == SDA_BF16)
-    hipLaunchKernelGGL(sa_weights_fwd_kernel<uint16_t>, dim3(D1p), dim3(256), 0, st, z, cos_t, sin_t, mask, W, (uint16_t*)Wp, D1, K2, C, Cp);
+    hipLaunchKernelGGL(sa_fwd_final_kernel<uint16_t>, dim3(D1p), dim3(256), 0, st, scratch, nchunk, mask, W, (uint16_t*)Wp, D1, C, Cp);
   else { set_error("sa_weights_forward: unknown dtype"); return -1; }
   return check_launch("sa_weights_forward");
 }
@@ -215,7 +253,8 @@ extern "C" int sda_sa_weights_forward(const float* z, const float* cos_t, const 
 extern "C" int sda_sa_weights_backward(const float* dWd, const float* W, const float* mask, const float* cosT,
                                        const float* sinT, float* dz, int D1, int K2, int C, int Cp, void* stream) {
   if (!dWd || !W || !cosT || !sinT || !dz || C > 512) { set_error("sa_weights_backward: bad arguments"); return -1; }
-  hipLaunchKernelGGL(sa_weights_bwd_kernel, dim3(D1), dim3(256), 0, (hipStream_t)stream, dWd, W, mask, cosT, sinT, dz, D1, K2, C, Cp);
+  hipLaunchKernelGGL(sa_weights_bwd_kernel, dim3((D1 + SA_R - 1) / SA_R, (K2 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     dWd, W, mask, cosT, sinT, dz, D1, K2, C, Cp);
   return check_launch("sa_weights_backward");
 }
 

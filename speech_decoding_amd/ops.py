@@ -399,7 +399,8 @@ def sa_weights_forward(z, cos_t, sin_t, mask, D1p, Cp, dtype):
     zr = torch.view_as_real(z).contiguous()
     W = torch.empty((D1, Cc), dtype=torch.float32, device=z.device)
     Wp = torch.empty((1, 1, D1p, Cp), dtype=dtype, device=z.device)
-    L.check(L.load().sda_sa_weights_forward(_p(zr), _p(cos_t), _p(sin_t), _p(mask), _p(W), _p(Wp), D1, K2, Cc, D1p, Cp,
+    scratch = torch.empty(L.load().sda_sa_scratch_floats(D1, K2, Cc), dtype=torch.float32, device=z.device)
+    L.check(L.load().sda_sa_weights_forward(_p(zr), _p(cos_t), _p(sin_t), _p(mask), _p(W), _p(Wp), _p(scratch), D1, K2, Cc, D1p, Cp,
                                             dt_code(dtype), _st()), "sa_weights_forward")
     return W, Wp
 
