@@ -419,14 +419,16 @@ class ClipCtx:
 
 
 def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: int, Bn: int, T: int, col0: int = 0,
-                 reduction: str = "mean", B_global: Optional[int] = None, dist_group=None, want_grad: bool = True):
+                 reduction: str = "mean", B_global: Optional[int] = None, dist_group=None, want_grad: bool = True,
+                 ysq: Optional[torch.Tensor] = None):
     """CLIP loss (loss.py:58-79) on RL embeddings: Yt holds the Bm (global) speech rows, Zt the Bn local
     brain rows.  Returns (loss_local_share, logits, ranks_count, ctx).  With `dist_group`, row statistics
     and the diagonal are merged across ranks so that the negatives span the global batch."""
     import torch.distributed as dist
     Fp = Zt.shape[1]
     row_elems = L.rows_tp(T) * Fp
-    ysq = ops.rows_sumsq(Yt, Bm, row_elems, row_elems)
+    if ysq is None:                              # (under DP the caller gathers the per-rank norms instead)
+        ysq = ops.rows_sumsq(Yt, Bm, row_elems, row_elems)
     zsq = ops.rows_sumsq(Zt, Bn, row_elems, row_elems)
     S = ops.matmul_nt_splitk(Yt, Zt, Bm, Bn, row_elems, row_elems)
     logits, row_max, row_sum, col_lse, diag = ops.clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0)

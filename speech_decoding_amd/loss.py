@@ -91,20 +91,23 @@ def _dist_group():
 
 def gather_speech_rows(Yt_local: torch.Tensor, B: int, T: int, group, async_op: bool = False):
     """All-gather the packed speech rows of every rank (RCCL all_gather over xGMI; samples are contiguous
-    blocks of Tp rows, so the gather lands directly in RL order).  Returns (Yt, Bm, col0, B_global[, work])."""
+    blocks of Tp rows, so the gather lands directly in RL order) together with their squared norms (computed
+    once, on the rank that owns the rows).  Returns (Yt, ysq, Bm, col0, B_global, works)."""
+    row_elems = L.rows_tp(T) * Yt_local.shape[1]
+    ysq_local = ops.rows_sumsq(Yt_local, B, row_elems, row_elems)
     if group is None:
-        return (Yt_local, B, 0, B, None) if async_op else (Yt_local, B, 0, B)
+        return Yt_local, ysq_local, B, 0, B, []
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     Tp = L.rows_tp(T)
     Yt = _ring_rows("loss.Yall", B * world, Yt_local.shape[1], T, Yt_local.dtype, Yt_local.device)
-    work = dist.all_gather_into_tensor(Yt[: B * world * Tp], Yt_local[: B * Tp], group=group, async_op=async_op)
-    if async_op:
-        return Yt, B * world, rank * B, B * world, work
-    return Yt, B * world, rank * B, B * world
+    ysq = torch.empty(B * world, dtype=torch.float32, device=Yt_local.device)
+    w1 = dist.all_gather_into_tensor(Yt[: B * world * Tp], Yt_local[: B * Tp], group=group, async_op=async_op)
+    w2 = dist.all_gather_into_tensor(ysq, ysq_local, group=group, async_op=async_op)
+    return Yt, ysq, B * world, rank * B, B * world, ([w1, w2] if async_op else [])
 
 
-_prefetched = []          # [(weakref(Y), dtype, Yt, Bm, col0, Bg, work)] — at most one pending prefetch
+_prefetched = []          # [(weakref(Y), dtype, Yt, ysq, Bm, col0, Bg, works)] — at most one pending prefetch
 
 
 def prefetch_speech(Y: torch.Tensor, dtype=None, global_negatives: bool = True):
@@ -115,18 +118,18 @@ def prefetch_speech(Y: torch.Tensor, dtype=None, global_negatives: bool = True):
     dtype = dtype or torch.float32
     Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y")
     group = _dist_group() if global_negatives else None
-    Yt, Bm, col0, Bg, work = gather_speech_rows(Yt_local, B, T, group, async_op=True)
+    Yt, ysq, Bm, col0, Bg, works = gather_speech_rows(Yt_local, B, T, group, async_op=True)
     _prefetched.clear()
-    _prefetched.append((weakref.ref(Y), dtype, Yt, Bm, col0, Bg, work))
+    _prefetched.append((weakref.ref(Y), dtype, Yt, ysq, Bm, col0, Bg, works))
 
 
 def _take_prefetched(Y, dtype):
-    for wy, dt, Yt, Bm, col0, Bg, work in _prefetched:
+    for wy, dt, Yt, ysq, Bm, col0, Bg, works in _prefetched:
         if wy() is Y and dt == dtype:
             _prefetched.clear()
-            if work is not None:
+            for work in works:
                 work.wait()                     # current stream waits for RCCL's stream; the host does not block
-            return Yt, Bm, col0, Bg
+            return Yt, ysq, Bm, col0, Bg
     return None
 
 
@@ -140,12 +143,12 @@ class _ClipFn(torch.autograd.Function):
         group = _dist_group() if module.global_negatives else None
         pre = _take_prefetched(Y, dtype)
         if pre is not None:
-            Yt, Bm, col0, Bg = pre
+            Yt, ysq, Bm, col0, Bg = pre
         else:
             Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y")
-            Yt, Bm, col0, Bg = gather_speech_rows(Yt_local, B, T, group)
+            Yt, ysq, Bm, col0, Bg, _ = gather_speech_rows(Yt_local, B, T, group)
         loss, logits, cnt, cctx = E.clip_forward(Yt, Zt, temp.detach(), Bm=Bm, Bn=B, T=T, col0=col0,
-                                                 reduction=module.reduction, B_global=Bg, dist_group=group)
+                                                 reduction=module.reduction, B_global=Bg, dist_group=group, ysq=ysq)
         if group is not None:
             dist.all_reduce(cnt, group=group)
             dist.all_reduce(loss, group=group)          # report the global loss; backward uses the local share
@@ -214,8 +217,8 @@ def retrieval_ranks(Y: torch.Tensor, Z: torch.Tensor, global_candidates: bool = 
     Yt = as_rows(Y, B, F, T, dtype, "Y")
     temp = torch.zeros(1, dtype=torch.float32, device=Zt.device)
     group = _dist_group() if global_candidates else None     # under data parallelism: the GLOBAL batch
-    Yt, Bm, col0, Bg = gather_speech_rows(Yt, B, T, group)
-    _, _, cnt, _ = E.clip_forward(Yt, Zt, temp, Bm=Bm, Bn=B, T=T, col0=col0, B_global=Bg, dist_group=group)
+    Yt, ysq, Bm, col0, Bg, _ = gather_speech_rows(Yt, B, T, group)
+    _, _, cnt, _ = E.clip_forward(Yt, Zt, temp, Bm=Bm, Bn=B, T=T, col0=col0, B_global=Bg, dist_group=group, ysq=ysq)
     if group is not None:
         import torch.distributed as dist
         dist.all_reduce(cnt, group=group)
