@@ -110,6 +110,11 @@ typedef struct sda_conv_args {
   const int32_t* widx;  /* [B] weight selector per sample (device), or NULL */
   float* stats;         /* [B * n_t_tiles][2][Cout_p] per-tile (sum, sum of squares) over valid rows, or NULL */
   float* partial;       /* ksplit > 1: [ksplit][T][Cout_p] fp32 raw accumulators (B must be 1) */
+  const void* bn_x;     /* optional RL [rows][Cout_p]: input of the BatchNorm+GELU whose OUTPUT gradient this conv
+                         * produces (data-gradient convs).  With bn_x, `stats` receives the per-tile sums of the
+                         * BatchNorm backward instead: [tile][0][c] = sum dg, [tile][1][c] = sum dg * xhat, with
+                         * dg = y * GELU'(gamma * xhat + beta), xhat = (bn_x - mean) * rstd, y as stored */
+  const float* bn_coef; /* with bn_x: [4][Cout_p] = gamma, beta, mean, rstd (zero on padded channels) */
   int B, T, Cin_p, Cout_p, KS, dil;
   long x_pitch, w_pitch; /* elements per row of x / per output-channel row of w */
   long x_row0;           /* first row of sample 0 (SDA_ROW_PAD for RL, 0 for plain matrices) */
@@ -128,7 +133,8 @@ int sda_conv_n_t_tiles(int T);
  * running stats: scale/shift are derived from them. */
 int sda_bn_finalize(const float* partial, int ntiles, double count, const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean, float* running_var, float* mean,
-                    float* rstd, float* scale, float* shift, int C, int Cp, int training, void* stream);
+                    float* rstd, float* scale, float* shift, float* bwd_coef /* optional [4][Cp]: gamma, beta,
+                    mean, rstd for sda_conv_args.bn_coef */, int C, int Cp, int training, void* stream);
 /* y = GELU(x * scale[c] + shift[c]) on valid rows */
 int sda_bn_gelu_forward(const void* x, void* y, const float* scale, const float* shift, int B, int T,
                         int Cp, int dtype, void* stream);
@@ -140,6 +146,9 @@ int sda_bn_gelu_forward(const void* x, void* y, const float* scale, const float*
 int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, int C, float* partial, float* dgamma,
                                 float* dbeta, int B, int T, int Cp, int dtype, void* stream);
+/* out0[c] = sum_k partial[k][0][c] (and out1 from [k][1][c] when out1 != NULL): fixed-order fp64 reduction of
+ * per-tile statistics written by sda_conv_gemm (`stats`), e.g. the BatchNorm backward sums of bn_x mode. */
+int sda_reduce_stats(const float* partial, int nrows, float* out0, float* out1, int Cp, void* stream);
 int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean, const float* rstd,
                                const float* gamma, const float* beta, int C, const float* dgamma,
                                const float* dbeta, double count, float* coef /* 6*Cp floats scratch */, void* dx,

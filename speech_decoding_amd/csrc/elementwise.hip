@@ -186,39 +186,49 @@ __global__ void unpack_vector_kernel(const float* __restrict__ g, float* __restr
 // ------------------------------------------------------------------------------------------------
 // BatchNorm1d: finalize / apply+GELU / backward   (models.py:135,143,158,161)
 // ------------------------------------------------------------------------------------------------
-// Sum partial[k][which][c] over k for the 8 channels of this block: 32 thread groups stride over k,
-// fp64 accumulation, fixed combination order (deterministic).  Result valid for threadIdx.x < 8.
-__device__ inline void block_partial_sums(const float* __restrict__ partial, int n, int Cp, int c, bool two,
+// Sum partial[k][which][c] over k for the 8 channels of this block: 128 thread groups (2 lanes x float4
+// each) stride over k, fp64 accumulation, fixed combination order (deterministic).  Result: channel
+// 8*blockIdx.x + threadIdx.x on threads 0..7.
+__device__ inline void block_partial_sums(const float* __restrict__ partial, int n, int Cp, int cbase, bool two,
                                           double& s0, double& s1) {
-  __shared__ double sh[2][32][8];
-  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
-  double a0 = 0.0, a1 = 0.0;
-  if (c < Cp) {
-#pragma unroll 8
-    for (int k = ty; k < n; k += 32) {
-      a0 += (double)partial[((size_t)k * 2 + 0) * Cp + c];
-      if (two) a1 += (double)partial[((size_t)k * 2 + 1) * Cp + c];
+  __shared__ double sh[2][128][8];
+  const int tx = threadIdx.x & 1, ty = threadIdx.x >> 1;
+  double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+  const int c4 = cbase + tx * 4;
+  if (c4 < Cp) {
+#pragma unroll 4
+    for (int k = ty; k < n; k += 128) {
+      const float4 u = *reinterpret_cast<const float4*>(partial + ((size_t)k * 2 + 0) * Cp + c4);
+      a0[0] += (double)u.x; a0[1] += (double)u.y; a0[2] += (double)u.z; a0[3] += (double)u.w;
+      if (two) {
+        const float4 v = *reinterpret_cast<const float4*>(partial + ((size_t)k * 2 + 1) * Cp + c4);
+        a1[0] += (double)v.x; a1[1] += (double)v.y; a1[2] += (double)v.z; a1[3] += (double)v.w;
+      }
     }
   }
-  sh[0][ty][tx] = a0;
-  sh[1][ty][tx] = a1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sh[0][ty][tx * 4 + j] = a0[j]; sh[1][ty][tx * 4 + j] = a1[j]; }
   __syncthreads();
   s0 = 0.0; s1 = 0.0;
-  if (ty == 0) {
-#pragma unroll
-    for (int g = 0; g < 32; ++g) { s0 += sh[0][g][tx]; s1 += sh[1][g][tx]; }
+  if (threadIdx.x < 8) {
+    for (int g = 0; g < 128; ++g) { s0 += sh[0][g][threadIdx.x]; s1 += sh[1][g][threadIdx.x]; }
   }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* mean_o,
-                                   float* rstd_o, float* scale_o, float* shift_o, int C, int Cp, int training) {
+                                   float* rstd_o, float* scale_o, float* shift_o, float* bwd_coef, int C, int Cp,
+                                   int training) {
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double s = 0.0, q = 0.0;
-  if (training) block_partial_sums(partial, ntiles, Cp, c, true, s, q);
+  if (training) block_partial_sums(partial, ntiles, Cp, blockIdx.x * 8, true, s, q);
   if (threadIdx.x >= 8 || c >= Cp) return;
-  if (c >= C) { mean_o[c] = 0.f; rstd_o[c] = 0.f; scale_o[c] = 0.f; shift_o[c] = 0.f; return; }
+  if (c >= C) {
+    mean_o[c] = 0.f; rstd_o[c] = 0.f; scale_o[c] = 0.f; shift_o[c] = 0.f;
+    if (bwd_coef) { bwd_coef[c] = 0.f; bwd_coef[Cp + c] = 0.f; bwd_coef[2 * Cp + c] = 0.f; bwd_coef[3 * Cp + c] = 0.f; }
+    return;
+  }
   double mean, var;
   if (training) {
     mean = s / count;
@@ -239,6 +249,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   rstd_o[c] = (float)rstd;
   scale_o[c] = (float)sc;
   shift_o[c] = (float)((double)beta[c] - mean * sc);
+  if (bwd_coef) {
+    bwd_coef[c] = gamma[c]; bwd_coef[Cp + c] = beta[c]; bwd_coef[2 * Cp + c] = (float)mean; bwd_coef[3 * Cp + c] = (float)rstd;
+  }
 }
 
 template <typename E>
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(256) void col_reduce_final_kernel(const float* __re
                                                                float* __restrict__ out0, float* __restrict__ out1, int Cp) {
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double s0, s1;
-  block_partial_sums(partial, nblocks, Cp, c, out1 != nullptr, s0, s1);
+  block_partial_sums(partial, nblocks, Cp, blockIdx.x * 8, out1 != nullptr, s0, s1);
   if (threadIdx.x >= 8 || c >= Cp) return;
   out0[c] = (float)s0;
   if (out1) out1[c] = (float)s1;
@@ -676,12 +689,14 @@ extern "C" int sda_unpack_vector(const float* g, float* dst, int C, int Cp, int 
 
 extern "C" int sda_bn_finalize(const float* partial, int ntiles, double count, const float* gamma, const float* beta,
                                float eps, float momentum, float* running_mean, float* running_var, float* mean,
-                               float* rstd, float* scale, float* shift, int C, int Cp, int training, void* stream) {
+                               float* rstd, float* scale, float* shift, float* bwd_coef, int C, int Cp, int training,
+                               void* stream) {
   if (!gamma || !beta || !mean || !rstd || !scale || !shift || C > Cp) { set_error("bn_finalize: bad arguments"); return -1; }
   if (training && (!partial || ntiles < 1 || count < 1.0)) { set_error("bn_finalize: training mode needs partial statistics"); return -1; }
   if (!training && (!running_mean || !running_var)) { set_error("bn_finalize: eval mode needs running statistics"); return -1; }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, ntiles, count,
-                     gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, C, Cp, training);
+                     gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, bwd_coef, C, Cp,
+                     training);
   return check_launch("bn_finalize");
 }
 
@@ -710,6 +725,13 @@ extern "C" int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const 
                                          (const E*)x, mean, rstd, gamma, beta, C, partial, B, T, Cp));
   hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, partial, nb, dbeta, dgamma, Cp);
   return check_launch("bn_gelu_backward_reduce");
+}
+
+extern "C" int sda_reduce_stats(const float* partial, int nrows, float* out0, float* out1, int Cp, void* stream) {
+  if (!partial || !out0 || nrows < 1 || Cp % 8) { set_error("reduce_stats: bad arguments"); return -1; }
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, nrows,
+                     out0, out1, Cp);
+  return check_launch("reduce_stats");
 }
 
 extern "C" int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean, const float* rstd,

@@ -73,6 +73,10 @@ template <> struct Vec16<float> {
   }
   __device__ static void store(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
   __device__ static float round(float x) { return x; }
+  __device__ static uint4 load_raw(const float* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ static void unpack(const uint4& u, float* v) {
+    v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y); v[2] = __uint_as_float(u.z); v[3] = __uint_as_float(u.w);
+  }
 };
 template <> struct Vec16<uint16_t> {
   static constexpr int N = 8;
@@ -89,6 +93,13 @@ template <> struct Vec16<uint16_t> {
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
   __device__ static float round(float x) { return bf2f(f2bf(x)); }
+  // 16 bytes kept packed (4 registers) until use: halves the registers of prefetched rows
+  __device__ static uint4 load_raw(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ static void unpack(const uint4& u, float* v) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
 };
 
 // Byte offset of 16-byte chunk `chunk` (0..7) of 128-byte LDS row `row`, XOR-swizzled so that 16

@@ -12,15 +12,30 @@
 // all KS taps and streams its segment's samples in 64-row chunks; the three taps read the same staged x
 // image at row offsets tap*dil.  Segments make the K split explicit: per-subject weight gradients use one
 // segment per subject (final result, no reduction), shared weights use ~CU-count segments + reduce_slabs.
+#include <stdlib.h>
+
 #include "sd_common.h"
 
 namespace sda {
 
 
-// Rows staged per K-chunk = two MFMA K-steps: 64 rows (bf16, 32 per step) / 32 rows (fp32, 16 per step).
+// Rows per MFMA K-step: 32 (bf16) / 16 (fp32).  A staged K-chunk holds KM of them.
 template <typename E> struct WK;
-template <> struct WK<uint16_t> { static constexpr int KSTEP = 32, KT = 64; };
-template <> struct WK<float> { static constexpr int KSTEP = 16, KT = 32; };
+template <> struct WK<uint16_t> { static constexpr int KSTEP = 32; };
+template <> struct WK<float> { static constexpr int KSTEP = 16; };
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the immediate must be a literal); anything above the
+// table waits for everything, which is always safe.
+__device__ inline void wait_vmcnt_dyn(int n) {
+#define SDA_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    SDA_VMC(1) SDA_VMC(2) SDA_VMC(3) SDA_VMC(4) SDA_VMC(5) SDA_VMC(6) SDA_VMC(7) SDA_VMC(8) SDA_VMC(9) SDA_VMC(10)
+    SDA_VMC(11) SDA_VMC(12) SDA_VMC(13) SDA_VMC(14) SDA_VMC(15) SDA_VMC(16) SDA_VMC(17) SDA_VMC(18) SDA_VMC(19)
+    SDA_VMC(20) SDA_VMC(21) SDA_VMC(22) SDA_VMC(23) SDA_VMC(24)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef SDA_VMC
+}
 
 typedef __attribute__((address_space(1))) const void gmem_cv;
 typedef __attribute__((address_space(3))) void lds_v;
@@ -81,28 +96,29 @@ template <int RB> struct TrOp<float, RB> {
 
 // TN = ci columns per workgroup: 64 for KS = 3 (three accumulator sets), 128 for KS = 1 (wave tile
 // TILE_M/2 x 64: fewer LDS bytes per MFMA and half as many re-reads of dy).
-template <typename E, int TILE_M, int KS, int TN> struct WGeom {
-  static constexpr int KT = WK<E>::KT;
+// KM = MFMA K-steps per staged chunk, NS = LDS stages (NS - 1 chunks of LDS-DMA in flight behind the MFMAs).
+template <typename E, int TILE_M, int KS, int TN, int KM, int NS> struct WGeom {
+  static constexpr int KT = WK<E>::KSTEP * KM;
   static constexpr int RB_M = TILE_M * (int)sizeof(E);          // dy image row bytes
   static constexpr int RB_N = TN * (int)sizeof(E);              // x image row bytes
   static constexpr int DY_BYTES = KT * RB_M;
-  static constexpr int XR = KT + 2 * PAD;
+  static constexpr int XR = KT + (KS == 3 ? 2 * PAD : 0);
   static constexpr int X_BYTES = XR * RB_N;
   static constexpr int STAGE = DY_BYTES + X_BYTES;
   static constexpr int DY_PIECES = DY_BYTES / 1024;
   static constexpr int EPI_BYTES = TILE_M * (TN + 4) * 4;
-  static constexpr int LDS = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  static constexpr int LDS = (NS * STAGE > EPI_BYTES) ? NS * STAGE : EPI_BYTES;
   static_assert(DY_BYTES % 1024 == 0 && X_BYTES % 1024 == 0, "images must be whole 1 KB pieces");
 };
 
-template <typename E, int TILE_M, int KS, int TN>
-__global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args a) {
+template <typename E, int TILE_M, int KS, int TN, int KM, int NS>
+__global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 1024) ? 1 : 2) void wgrad_gemm_kernel(const sda_wgrad_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using G = WGeom<E, TILE_M, KS, TN>;
+  using G = WGeom<E, TILE_M, KS, TN, KM, NS>;
   constexpr int WG_TN = TN;
   constexpr int NREP = TN / 32;                             // 16-column n tiles per wave (wave tile = TILE_M/2 x TN/2)
   constexpr int PER16 = Elem<E>::PER16;
-  constexpr int KSTEP = WK<E>::KSTEP, KT = WK<E>::KT;
+  constexpr int KSTEP = WK<E>::KSTEP, KT = G::KT;
   constexpr int MREP = TILE_M / 32;                         // 16-row m tiles per wave (wave tile = TILE_M/2 x 32)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -181,13 +197,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
     }
   };
 
-  if (total > 0) stage(0, 0);
+  // this wave's LDS-DMA pieces per chunk (asm DMA is not tracked by hipcc: the counted waits below are ours)
+  const int my_pieces = ((G::DY_PIECES - wid + 3) >> 2) + ((x_pieces - wid + 3) >> 2);
+  const int keep = (NS - 2) * my_pieces;                  // pieces of younger chunks that may still be in flight
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < total) stage(s, s);
+  int cur = 0;
   for (int it = 0; it < total; ++it) {
-    const int cur = it & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own DMA pieces of chunk `it` landed (asm DMA: not tracked by hipcc)
+    if (NS > 2 && it + NS - 2 < total) wait_vmcnt_dyn(keep);   // own pieces of chunk `it` landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // everyone's landed; chunk it-1 fully consumed
-    if (it + 1 < total) stage(it + 1, cur ^ 1);
+    if (it + NS - 1 < total) stage(it + NS - 1, (cur + NS - 1) % NS);
     const unsigned char* dys = smem + cur * G::STAGE;
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
     const unsigned char* xs = dys + G::DY_BYTES;
 #pragma unroll
     for (int kk = 0; kk < KT / KSTEP; ++kk) {
@@ -256,11 +279,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const sda_wgrad_args
   }
 }
 
-template <typename E, int TILE_M, int KS, int TN>
+template <typename E, int TILE_M, int KS, int TN, int KM = 2, int NS = 2>
 static int launch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
-  constexpr int lds = WGeom<E, TILE_M, KS, TN>::LDS;
+  constexpr int lds = WGeom<E, TILE_M, KS, TN, KM, NS>::LDS;
   static bool attr_done = false;
-  auto kern = wgrad_gemm_kernel<E, TILE_M, KS, TN>;
+  auto kern = wgrad_gemm_kernel<E, TILE_M, KS, TN, KM, NS>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             lds) != hipSuccess) {
@@ -274,10 +297,33 @@ static int launch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
   return check_launch("wgrad_gemm");
 }
 
+static int wgrad_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SDA_WGRAD_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 template <typename E, int TILE_M>
 static int dispatch_wgrad_m(const sda_wgrad_args& a, hipStream_t st) {
-  if (a.KS == 3) return launch_wgrad<E, TILE_M, 3, 64>(a, st);
-  if (a.Cin_p % 128 == 0) return launch_wgrad<E, TILE_M, 1, 128>(a, st);
+  const int v = wgrad_variant();
+  if (a.KS == 3) {
+    if constexpr (TILE_M == 160) {
+      if (v == 1) return launch_wgrad<E, TILE_M, 3, 64, 2, 3>(a, st);
+      if (v == 2) return launch_wgrad<E, TILE_M, 3, 64, 1, 4>(a, st);
+      if (v == 3) return launch_wgrad<E, TILE_M, 3, 64, 1, 3>(a, st);
+      if (v == 4) return launch_wgrad<E, TILE_M, 3, 64, 2, 4>(a, st);
+    }
+    return launch_wgrad<E, TILE_M, 3, 64>(a, st);
+  }
+  if (a.Cin_p % 128 == 0) {
+    if constexpr (TILE_M == 128) {
+      if (v == 1) return launch_wgrad<E, TILE_M, 1, 128, 2, 3>(a, st);
+      if (v == 2) return launch_wgrad<E, TILE_M, 1, 128, 1, 4>(a, st);
+      if (v == 3) return launch_wgrad<E, TILE_M, 1, 128, 1, 3>(a, st);
+      if (v == 4) return launch_wgrad<E, TILE_M, 1, 128, 2, 4>(a, st);
+    }
+    return launch_wgrad<E, TILE_M, 1, 128>(a, st);
+  }
   return launch_wgrad<E, TILE_M, 1, 64>(a, st);
 }
 

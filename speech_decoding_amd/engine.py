@@ -75,6 +75,7 @@ class EncoderEngine:
         self._seg_cache: Dict[tuple, tuple] = {}
         self._gen = 0
         self.reuse_workspace = True
+        self.fuse_bn_backward_stats = True   # BatchNorm-backward sums in the data-gradient conv's epilogue
         self.wgrad_target_wgs = 256          # workgroups per weight-gradient launch (split over sample segments)
         # weight-gradient chains (wgrad_gemm -> reduce_slabs -> unpack) depend only on dy and a saved
         # activation, never on each other or on the data-gradient chain: run them on a second HIP stream
@@ -226,13 +227,15 @@ class EncoderEngine:
                         stats = ops.reduce_slabs(stats).reshape(1, 2, d.D2p)
                         self._allreduce(stats)
                         nt = 1
-                    mean, rstd, scale, shift = ops.bn_finalize(stats, nt, count, P[bnp + "w"], P[bnp + "b"],
-                                                               P[bnp + "rm"], P[bnp + "rv"], d.D2p, True, eps, momentum)
+                    mean, rstd, scale, shift, bcoef = ops.bn_finalize(stats, nt, count, P[bnp + "w"], P[bnp + "b"],
+                                                                      P[bnp + "rm"], P[bnp + "rv"], d.D2p, True, eps, momentum,
+                                                                      want_bwd_coef=True)
                 else:
+                    bcoef = None
                     ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, alg_dims=alg)
                     mean, rstd, scale, shift = ops.bn_finalize(None, 0, count, P[bnp + "w"], P[bnp + "b"],
                                                                P[bnp + "rm"], P[bnp + "rv"], d.D2p, False, eps, momentum)
-                ctx.bn[bnp] = (mean, rstd)
+                ctx.bn[bnp] = (mean, rstd, bcoef)
                 a = ops.bn_gelu_forward(h, rows(f"b{k}.a{j}", d.D2p), scale, shift, B, T)
                 bufs[f"b{k}.h{j}"], bufs[f"b{k}.a{j}"] = h, a
                 x = a
@@ -325,20 +328,30 @@ class EncoderEngine:
                 return ops.reduce_unpack_wgrad(slabs, Cout, Cin, KS, **glu)
             return on_side(chain)
 
-        def dgrad(dy, key, w_fp32, Cout_p, Cin_p, out, KS, dil, res=None, widx=None, **glu):
-            return ops.conv_gemm(dy, ctx.packed_T[key], out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx,
-                                 alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]))
+        ntile = B * ops.n_t_tiles(T)
+
+        def dgrad(dy, key, w_fp32, Cout_p, Cin_p, out, KS, dil, res=None, widx=None, bn=None, **glu):
+            """Data-gradient conv.  bn = (h, coef): `out` is the gradient entering GELU(BN(h)); the conv's epilogue
+            then also emits the per-tile BatchNorm-backward sums (returned as second value) — the separate
+            reduction pass over (out, h) is not needed."""
+            if bn is None or not self.fuse_bn_backward_stats or bn[1] is None:
+                return ops.conv_gemm(dy, ctx.packed_T[key], out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx,
+                                     alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2])), None
+            st = torch.empty((ntile, 2, out.shape[1]), dtype=torch.float32, device=dev)
+            ops.conv_gemm(dy, ctx.packed_T[key], out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx, stats=st,
+                          bn_x=bn[0], bn_coef=bn[1], alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]))
+            return out, st
 
         # ---- final projections
         du2 = tmp("du2", d.Fp)
         cs = ops.gelu_backward_colsum(bufs["u2"], dZt, du2, B, T, scratch)
         grads["f2b"] = ops.unpack_vector(cs, d.F)
-        dg1 = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
+        dg1, _ = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
         grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
         du1 = tmp("du1", d.F1p)
         cs = ops.gelu_backward_colsum(bufs["u1"], dg1, du1, B, T, scratch)
         grads["f1b"] = ops.unpack_vector(cs, d.F1)
-        dx = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
+        dx, _ = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
         grads["f1w"] = wgrad(du1, bufs["x5"], 1, 0, d.F1, d.D2)
         flush(["f2w", "f2b", "f1w", "f1b"])
 
@@ -352,19 +365,20 @@ class EncoderEngine:
             dc2 = tmp(f"dc2.{k}", 2 * d.D2p)          # per-layer buffers: a side-stream wgrad may still read them
             cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
             grads[f"b{k}.c2b"] = ops.unpack_vector(cs, 2 * d.D2, **glu)
-            da1 = dgrad(dc2, f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2], **glu)
+            da1, tstats = dgrad(dc2, f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2],
+                                bn=(bufs[f"b{k}.h1"], ctx.bn[f"b{k}.bn1"][2]), **glu)
             # the weight-gradient chain is queued AFTER the data-gradient conv: on the side stream it then runs
             # beside the HBM-bound BatchNorm backward kernels that follow, not beside the MFMA-bound conv
             grads[f"b{k}.c2w"] = wgrad(dc2, bufs[f"b{k}.a1"], 3, dil[2], 2 * d.D2, d.D2, **glu)
             x_in = bufs[f"x{k}"]
             for j in (1, 0):
                 bnp = f"b{k}.bn{j}"
-                mean, rstd = ctx.bn[bnp]
+                mean, rstd, _ = ctx.bn[bnp]
                 dh = tmp(f"dh.{k}.{j}", d.D2p)
                 world = self.world
                 dgam, dbet = ops.bn_gelu_backward(da1, bufs[f"b{k}.h{j}"], mean, rstd, P[bnp + "w"], P[bnp + "b"], dh, B, T,
                                                   scratch, count=float(B) * T * world,
-                                                  allreduce=self._allreduce if world > 1 else None)
+                                                  allreduce=self._allreduce if world > 1 else None, tile_stats=tstats)
                 # under DP the sums are already global on every rank; the gradient all-reduce (SUM) follows
                 if world > 1:
                     dgam, dbet = dgam / world, dbet / world
@@ -376,7 +390,8 @@ class EncoderEngine:
                 grads[f"b{k}.c{j}b"] = null_bias[2 * k + j]
                 res = dh if (j == 1 or k > 0) else None
                 out = tmp("da", d.D2p) if j == 1 else tmp("dxB" if flip == 0 else "dxA", ci_p)
-                da1 = dgrad(dh, f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res)
+                da1, tstats = dgrad(dh, f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res,
+                                    bn=(bufs[f"b{k}.h0"], ctx.bn[f"b{k}.bn0"][2]) if j == 1 else None)
                 grads[f"b{k}.c{j}w"] = wgrad(dh, src, 3, dil[j], d.D2, ci)
             dx = da1
             flip ^= 1
@@ -388,10 +403,10 @@ class EncoderEngine:
         grads["subj_w"] = on_side(lambda: ops.unpack_conv_wgrad(
             ops.wgrad_gemm(dhs, bufs["h_c"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg, nseg=d.S),
             d.S, d.D1, d.D1, 1, d.D1p, d.D1p))
-        dh_c = dgrad(dhs, "subj_w", P["subj_w"], d.D1p, d.D1p, tmp("dh_c", d.D1p), 1, 0, widx=ctx.widx)
+        dh_c, _ = dgrad(dhs, "subj_w", P["subj_w"], d.D1p, d.D1p, tmp("dh_c", d.D1p), 1, 0, widx=ctx.widx)
         grads["sb_w"] = wgrad(dh_c, bufs["h_sa"], 1, 0, d.D1, d.D1)
         grads["sb_b"] = ops.unpack_vector(ops.colsum(dh_c, B, T, scratch), d.D1)
-        dh_sa = dgrad(dh_c, "sb_w", P["sb_w"], d.D1p, d.D1p, tmp("dh_sa", d.D1p), 1, 0)
+        dh_sa, _ = dgrad(dh_c, "sb_w", P["sb_w"], d.D1p, d.D1p, tmp("dh_sa", d.D1p), 1, 0)
         Cout_p, Cin_p = d.D1p, d.Cp
         tile_m = 160 if Cout_p % 160 == 0 else (128 if Cout_p % 128 == 0 else 64)
         perm, seg, nseg = self._uniform_segments(B, (Cout_p // tile_m) * (Cin_p // 64), dev)

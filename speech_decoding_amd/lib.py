@@ -21,7 +21,7 @@ vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
 class ConvArgs(C.Structure):
     _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("res", vp), ("y", vp), ("y_pre", vp), ("widx", vp),
-                ("stats", vp), ("partial", vp),
+                ("stats", vp), ("partial", vp), ("bn_x", vp), ("bn_coef", vp),
                 ("B", i32), ("T", i32), ("Cin_p", i32), ("Cout_p", i32), ("KS", i32), ("dil", i32),
                 ("x_pitch", i64), ("w_pitch", i64), ("x_row0", i64), ("x_sample_rows", i64),
                 ("x_rows_limit", i64), ("w_rows_limit", i32), ("ksplit", i32), ("flags", i32), ("dtype", i32)]
@@ -64,7 +64,8 @@ SIGNATURES = {
     "sda_unpack_vector": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sda_conv_gemm": (i32, [C.POINTER(ConvArgs), vp]),
     "sda_conv_n_t_tiles": (i32, [i32]),
-    "sda_bn_finalize": (i32, [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "sda_bn_finalize": (i32, [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "sda_reduce_stats": (i32, [vp, i32, vp, vp, i32, vp]),
     "sda_bn_gelu_forward": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_bn_gelu_backward_reduce": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_bn_gelu_backward_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, f64, vp, vp, i32, i32, i32, i32, vp]),

@@ -217,6 +217,7 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+_ENV_CONV_FLAGS = int(__import__("os").environ.get("SDA_CONV_FLAGS", "0"))     # experiments: 8192 = paired tiles
 
 
 def conv_tile_co(Cout_p: int) -> int:
@@ -224,14 +225,17 @@ def conv_tile_co(Cout_p: int) -> int:
 
 
 def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=None, stats=None, gelu=False,
-              alg_dims=None, dbg_flags=0):
+              alg_dims=None, dbg_flags=0, bn_x=None, bn_coef=None):
     """RL conv: x (rows, Cin_p), w (nW, KS, Cout_p, Cin_p) packed, y (rows, Cout_p).
     alg_dims = (Cin, Cout) unpadded, only used to count algorithmic FLOPs when the timer is on."""
     _need_cuda(x, w, y)
     a = L.ConvArgs()
     a.x, a.w, a.bias, a.res, a.y, a.y_pre = _p(x), _p(w), _p(bias), _p(res), _p(y), _p(y_pre)
     a.widx, a.stats, a.partial = _p(widx), _p(stats), None
+    a.bn_x, a.bn_coef = _p(bn_x), _p(bn_coef)
     a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = B, T, x.shape[1], y.shape[1], KS, dil
+    if bn_x is not None and (bn_x.shape != y.shape or bn_coef is None or bn_coef.numel() != 4 * y.shape[1] or stats is None):
+        raise L.SdaError("conv_gemm: bn_x needs the shape of y, a [4][Cout_p] coefficient table and a stats buffer")
     if w.shape[-1] != x.shape[1] or w.shape[-2] != y.shape[1] or w.shape[-3] != KS:
         raise L.SdaError(f"conv_gemm: weight {tuple(w.shape)} does not match x {tuple(x.shape)} / y {tuple(y.shape)}")
     a.x_pitch, a.w_pitch = x.shape[1], w.shape[-1]
@@ -239,7 +243,7 @@ def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=N
     if x.shape[0] < L.rows_alloc(B, T) or y.shape[0] < L.rows_alloc(B, T):
         raise L.SdaError("conv_gemm: RL buffers too small for (B, T)")
     a.w_rows_limit, a.ksplit = y.shape[1], 1
-    a.flags, a.dtype = (L.EPI_GELU if gelu else 0) | dbg_flags, dt_code(x.dtype)
+    a.flags, a.dtype = (L.EPI_GELU if gelu else 0) | dbg_flags | _ENV_CONV_FLAGS, dt_code(x.dtype)
     if TIMER is not None:
         cin, cout = alg_dims if alg_dims is not None else (x.shape[1], y.shape[1])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -281,13 +285,18 @@ def matmul_nt_splitk(xm: torch.Tensor, wm: torch.Tensor, M: int, N: int, K: int,
     return out
 
 
-def bn_finalize(partial, ntiles, count, gamma, beta, running_mean, running_var, Cp, training, eps=1e-5, momentum=0.1):
+def bn_finalize(partial, ntiles, count, gamma, beta, running_mean, running_var, Cp, training, eps=1e-5, momentum=0.1,
+                want_bwd_coef=False):
+    """Returns (mean, rstd, scale, shift[, bwd_coef]); bwd_coef = [4][Cp] (gamma, beta, mean, rstd), the table the
+    data-gradient conv reads in its BatchNorm-backward statistics mode."""
     dev = gamma.device
-    mean, rstd, scale, shift = (torch.empty(Cp, dtype=torch.float32, device=dev) for _ in range(4))
+    buf = torch.empty((8 if want_bwd_coef else 4, Cp), dtype=torch.float32, device=dev)
+    mean, rstd, scale, shift = buf[0], buf[1], buf[2], buf[3]
+    coef = buf[4:] if want_bwd_coef else None
     L.check(L.load().sda_bn_finalize(_p(partial), ntiles, float(count), _p(gamma), _p(beta), eps, momentum,
                                      _p(running_mean), _p(running_var), _p(mean), _p(rstd), _p(scale), _p(shift),
-                                     gamma.numel(), Cp, int(training), _st()), "bn_finalize")
-    return mean, rstd, scale, shift
+                                     _p(coef), gamma.numel(), Cp, int(training), _st()), "bn_finalize")
+    return (mean, rstd, scale, shift, coef) if want_bwd_coef else (mean, rstd, scale, shift)
 
 
 def bn_gelu_forward(x, y, scale, shift, B, T):
@@ -300,14 +309,19 @@ def reduce_scratch(Cp, device):
     return torch.empty(L.load().sda_reduce_scratch_floats(Cp), dtype=torch.float32, device=device)
 
 
-def bn_gelu_backward(dy, x, mean, rstd, gamma, beta, dx, B, T, scratch, count=None, allreduce=None):
-    """Returns (dgamma, dbeta) summed over `count` rows (global sums when `allreduce` is given) and fills dx."""
+def bn_gelu_backward(dy, x, mean, rstd, gamma, beta, dx, B, T, scratch, count=None, allreduce=None, tile_stats=None):
+    """Returns (dgamma, dbeta) summed over `count` rows (global sums when `allreduce` is given) and fills dx.
+    tile_stats: per-tile (sum dg, sum dg*xhat) already produced by the conv that wrote dy (conv_gemm(bn_x=...));
+    without it the sums take a pass of their own over dy and x."""
     Cp = x.shape[1]
     sums = torch.empty((2, Cp), dtype=torch.float32, device=x.device)
     dgamma, dbeta = sums[0], sums[1]
     lib = L.load()
-    L.check(lib.sda_bn_gelu_backward_reduce(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), gamma.numel(), _p(scratch),
-                                            _p(dgamma), _p(dbeta), B, T, Cp, dt_code(x.dtype), _st()), "bn_gelu_backward_reduce")
+    if tile_stats is not None:
+        L.check(lib.sda_reduce_stats(_p(tile_stats), tile_stats.shape[0], _p(dbeta), _p(dgamma), Cp, _st()), "reduce_stats")
+    else:
+        L.check(lib.sda_bn_gelu_backward_reduce(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), gamma.numel(), _p(scratch),
+                                                _p(dgamma), _p(dbeta), B, T, Cp, dt_code(x.dtype), _st()), "bn_gelu_backward_reduce")
     if allreduce is not None:
         allreduce(sums)
     coef = torch.empty(6 * Cp, dtype=torch.float32, device=x.device)

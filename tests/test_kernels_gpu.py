@@ -171,6 +171,49 @@ def test_conv3_dgrad_and_wgrad(ops, dtype, cin, cout, dil, T, glu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tiling", [4096, 8192])
+@pytest.mark.parametrize("cin,cout,dil,T", [(48, 40, 2, 70), (640, 320, 2, 300), (320, 320, 8, 360)])
+def test_conv3_bn_backward_statistics_epilogue(ops, dtype, cin, cout, dil, T, tiling):
+    """conv_gemm(bn_x=...) writes its output AND the BatchNorm+GELU backward sums of the layer that output is
+    the gradient of; they must equal the stand-alone reduction pass over the stored output."""
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(cin + cout + dil)
+    B = 3
+    Cin_p, Cout_p = L.pad_channels(cin), L.pad_channels(cout)
+    dyb = to_rows(ops, q(torch.randn(B, cin, T, generator=g), dtype), dtype)
+    w = q(torch.randn(cout, cin, 3, generator=g) / math.sqrt(3 * cin), dtype)
+    wp = ops.pack_conv_weight(w.to(DEV), Cout_p, Cin_p, dtype)
+    res = to_rows(ops, q(torch.randn(B, cout, T, generator=g), dtype), dtype)
+    h = to_rows(ops, q(torch.randn(B, cout, T, generator=g) * 1.3 + 0.2, dtype), dtype)      # the BN input
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(DEV)
+    beta = (torch.rand(cout, generator=g) - 0.5).to(DEV)
+    hs = ops.unpack_rows(h, B, cout, T)
+    part = torch.zeros((1, 2, Cout_p), device=DEV)
+    part[0, 0, :cout] = hs.sum(dim=(0, 2))
+    part[0, 1, :cout] = (hs ** 2).sum(dim=(0, 2))
+    mean, rstd, _, _, coef = ops.bn_finalize(part, 1, B * T, gamma, beta, torch.zeros(cout, device=DEV),
+                                             torch.ones(cout, device=DEV), Cout_p, True, want_bwd_coef=True)
+    np.testing.assert_array_equal(coef[2].cpu().numpy(), mean.cpu().numpy())
+    np.testing.assert_array_equal(coef[0, :cout].cpu().numpy(), gamma.cpu().numpy())
+    assert float(coef[:, cout:].abs().max()) == 0.0 if Cout_p > cout else True
+    out = ops.new_rows(B, T, Cout_p, dtype, DEV)
+    st = torch.full((B * ops.n_t_tiles(T), 2, Cout_p), float("nan"), device=DEV)
+    ops.conv_gemm(dyb, wp, out, B=B, T=T, KS=3, dil=dil, res=res, stats=st, bn_x=h, bn_coef=coef, dbg_flags=tiling)
+    plain = ops.new_rows(B, T, Cout_p, dtype, DEV)
+    ops.conv_gemm(dyb, wp, plain, B=B, T=T, KS=3, dil=dil, res=res, dbg_flags=tiling)
+    assert torch.equal(out, plain)                                   # the output itself is unchanged by the mode
+    dx1, dx2 = ops.new_rows(B, T, Cout_p, dtype, DEV), ops.new_rows(B, T, Cout_p, dtype, DEV)
+    dg_ref, db_ref = ops.bn_gelu_backward(out, h, mean, rstd, gamma, beta, dx1, B, T, ops.reduce_scratch(Cout_p, DEV))
+    dg, db = ops.bn_gelu_backward(out, h, mean, rstd, gamma, beta, dx2, B, T, ops.reduce_scratch(Cout_p, DEV), tile_stats=st)
+    scale = float(dg_ref.abs().max()) + 1e-6
+    # same fp32 terms, different summation order (per tile vs per row block): 1e-5 of the largest sum
+    assert float((dg - dg_ref).abs().max()) <= 1e-5 * scale * (1 if dtype == torch.float32 else 4)
+    assert float((db - db_ref).abs().max()) <= 1e-5 * (float(db_ref.abs().max()) + 1e-6) * (1 if dtype == torch.float32 else 4)
+    np.testing.assert_allclose(from_rows(ops, dx2, B, cout, T).numpy(), from_rows(ops, dx1, B, cout, T).numpy(),
+                               rtol=1e-3, atol=1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_wgrad_per_subject_segments(ops, dtype):
     from speech_decoding_amd import lib as L
     g = torch.Generator().manual_seed(8)
