@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
           if (a.flags & SDA_EPI_GELU) {
             if (ypre) Vec16<E>::store(ypre + off, v);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) v[j] = gelu_f(v[j]);
+            for (int j = 0; j < CH; ++j) v[j] = gelu_f<E>(v[j]);
           }
           Vec16<E>::store(yg + off, v);
           if constexpr (BN) {
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
               const float xh = (x8[j] - bmu[j]) * brs[j];
-              const float dg = Vec16<E>::round(v[j]) * gelu_grad_f(bga[j] * xh + bbe[j]);
+              const float dg = Vec16<E>::round(v[j]) * gelu_grad_f<E>(bga[j] * xh + bbe[j]);
               ssum[j] += dg;
               ssq[j] += dg * xh;
             }

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void bn_gelu_fwd_kernel(const E* __restrict__ 
       *reinterpret_cast<float4*>(sh + q4 * 4) = *reinterpret_cast<const float4*>(shift + ch * CH + q4 * 4);
     }
 #pragma unroll
-    for (int j = 0; j < CH; ++j) v[j] = gelu_f(v[j] * sc[j] + sh[j]);
+    for (int j = 0; j < CH; ++j) v[j] = gelu_f<E>(v[j] * sc[j] + sh[j]);
     Vec16<E>::store(y + off, v);
   }
 }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           const float xh = (xv[j] - mu[j]) * rs[j];
-          const float dg = dv[j] * gelu_grad_f(ga[j] * xh + be[j]);
+          const float dg = dv[j] * gelu_grad_f<E>(ga[j] * xh + be[j]);
           a0[j] += dg;
           a1[j] += dg * xh;
         }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
       Vec16<E>::load(x + row * xw + ch * CH, xv);
       if (MODE == 0) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) { o0[j] = d[j] * gelu_grad_f(xv[j]); a0[j] += o0[j]; }
+        for (int j = 0; j < CH; ++j) { o0[j] = d[j] * gelu_grad_f<E>(xv[j]); a0[j] += o0[j]; }
         Vec16<E>::store(dx + row * Ch + ch * CH, o0);
       } else {
         float g[CH];
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restr
     for (int j = 0; j < CH; ++j) {
       const float ga = cf[0][j], be = cf[1][j], mu = cf[2][j], rs = cf[3][j];
       const float xh = (xv[j] - mu) * rs;
-      const float g = d[j] * gelu_grad_f(ga * xh + be);
+      const float g = d[j] * gelu_grad_f<E>(ga * xh + be);
       o[j] = ga * rs * (g - cf[4][j] - xh * cf[5][j]);
     }
     Vec16<E>::store(dx + off, o);
@@ -527,8 +527,8 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const E* __restrict__ u, 
     const int b = vr / T, t = vr - (size_t)b * T;
     const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
     const float4 uv = load4(u + off), d = load4(dz + off);
-    store4(du + off, make_float4(d.x * gelu_grad_f(uv.x), d.y * gelu_grad_f(uv.y), d.z * gelu_grad_f(uv.z),
-                                 d.w * gelu_grad_f(uv.w)));
+    store4(du + off, make_float4(d.x * gelu_grad_f<E>(uv.x), d.y * gelu_grad_f<E>(uv.y), d.z * gelu_grad_f<E>(uv.z),
+                                 d.w * gelu_grad_f<E>(uv.w)));
   }
 }
 

@@ -123,12 +123,38 @@ template <> __device__ inline f32x4 mma16<float>(const uint4& a, const uint4& b,
   return c;
 }
 
-// exact (erf) GELU and its derivative — F.gelu default (models.py:158,161,194,195)
-__device__ inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ inline float gelu_grad_f(float x) {
+// GELU (erf form, F.gelu default — models.py:158,161,194,195) and its derivative, by storage type.
+// fp32 storage: libm erff, the exact path.  bf16 storage: the normal CDF by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute, 2^-9 is the storage resolution) — one v_rcp + one v_exp shared by the CDF and
+// the density, about a third of erff's instructions; the GELU kernels of the bf16 path are VALU-bound on erff.
+__device__ inline void normal_cdf_pdf(float x, float& cdf, float& pdf) {
+  const float e = __expf(-0.5f * x * x);                           // exp(-z^2), z = |x| / sqrt(2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float tail = 0.5f * p * t * e;                             // 0.5 * erfc(z)
+  cdf = x >= 0.f ? 1.0f - tail : tail;
+  pdf = 0.3989422804014327f * e;
+}
+template <typename E> __device__ inline float gelu_f(float x);
+template <typename E> __device__ inline float gelu_grad_f(float x);
+template <> __device__ inline float gelu_f<float>(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+template <> __device__ inline float gelu_grad_f<float>(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
   const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
+}
+template <> __device__ inline float gelu_f<uint16_t>(float x) {
+  float cdf, pdf;
+  normal_cdf_pdf(x, cdf, pdf);
+  return x * cdf;
+}
+template <> __device__ inline float gelu_grad_f<uint16_t>(float x) {
+  float cdf, pdf;
+  normal_cdf_pdf(x, cdf, pdf);
+  return fmaf(x, pdf, cdf);
 }
 __device__ inline float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 

@@ -76,7 +76,7 @@ class EncoderEngine:
         self._gen = 0
         self.reuse_workspace = True
         self.fuse_bn_backward_stats = True   # BatchNorm-backward sums in the data-gradient conv's epilogue
-        self.wgrad_target_wgs = 256          # workgroups per weight-gradient launch (split over sample segments)
+        self.wgrad_target_wgs = int(__import__('os').environ.get('SDA_WGRAD_WGS', 256))          # workgroups per weight-gradient launch (split over sample segments)
         # weight-gradient chains (wgrad_gemm -> reduce_slabs -> unpack) depend only on dy and a saved
         # activation, never on each other or on the data-gradient chain: run them on a second HIP stream
         self.wgrad_side_stream = True
