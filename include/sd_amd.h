@@ -36,7 +36,10 @@ enum { SDA_F32 = 0, SDA_BF16 = 1 };
 /* conv_gemm epilogue flags */
 enum { SDA_EPI_GELU = 1,
        SDA_CONV_SINGLE_TILE = 4096, /* force one 128-row tile per workgroup */
-       SDA_CONV_PAIR_TILES = 8192   /* two tiles per workgroup sharing one weight slab (default: one) */ };
+       SDA_CONV_PAIR_TILES = 8192,  /* two tiles per workgroup sharing one weight slab (default: one) */
+       SDA_CONV_PERSIST = 16384     /* kernel size 3, 160-channel tiles: persistent workgroups with the epilogue of
+                                       tile i issued inside the K loop of tile i+1 (conv3_persist.hip); silently
+                                       falls back to the tile-per-workgroup kernel for shapes it does not cover */ };
 
 int sda_abi_version(void);
 const char* sda_last_error(void);

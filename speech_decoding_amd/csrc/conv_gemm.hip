@@ -13,13 +13,10 @@
 // Epilogue: bias in registers -> LDS staging -> coalesced pass adding the residual, optional GELU,
 // BatchNorm partial statistics (per tile, deterministic), 8/16-byte stores.
 #include "sd_common.h"
+#include "conv_tile.h"
 
 namespace sda {
 
-// One LDS row = one MFMA K-step = 64 bytes (32 bf16 / 16 fp32 input channels).
-constexpr int ROW_B = 64;
-constexpr int XROWS = TILE_T + 2 * PAD;            // 160: worst-case halo
-constexpr int XS_BYTES = XROWS * ROW_B;            // 10 KB
 constexpr int EP_ROWS = 64;
 
 template <int TILE_CO, int CH = 4> struct EpiGeom {
@@ -38,14 +35,6 @@ template <int TILE_CO, int KS, int NT> constexpr int conv_lds_bytes() {
   constexpr int epi_b = NT * (EpiGeom<TILE_CO, 8>::EP_BYTES + EpiGeom<TILE_CO, 8>::RED_BYTES);   // CH = 8 is the larger
   return main_b > epi_b ? main_b : epi_b;
 }
-
-// 64-byte rows, 4 chunks of 16 bytes, chunk' = chunk ^ sw64(row) with sw64 = 2 * bit 2 of the row.
-// ds_read_b128 is serviced in four 16-lane groups that are NOT contiguous ({0-3,12-15,20-27}, {4-11,16-19,
-// 28-31}, ...): with lane = 16 * chunk + row the MFMA operand read puts rows {0-3,12-15} of one chunk and rows
-// {4-11} of the next chunk in one group, and this XOR lands them on 16 distinct 16-byte slots of the 256-byte
-// bank row for EVERY starting row (dilated taps start anywhere); measured SQ_LDS_BANK_CONFLICT = 0.
-__device__ inline int sw64(int row) { return (row >> 1) & 2; }
-__device__ inline int lds_sw64(int row, int chunk) { return row * ROW_B + ((chunk ^ sw64(row)) << 4); }
 
 typedef __attribute__((address_space(1))) const void gmem_cv;
 typedef __attribute__((address_space(3))) void lds_v;
@@ -463,6 +452,7 @@ static int dispatch_conv_nt(const sda_conv_args& a, hipStream_t st) {
 
 template <typename E>
 static int dispatch_conv(const sda_conv_args& a, hipStream_t st) {
+  if ((a.flags & SDA_CONV_PERSIST) && conv3_persist_supports(a)) return launch_conv3_persist(a, st);
   if (a.Cout_p % 160 == 0) return dispatch_conv_nt<E, 160>(a, st);
   if (a.Cout_p % 128 == 0) return dispatch_conv_nt<E, 128>(a, st);
   return dispatch_conv_nt<E, 64>(a, st);

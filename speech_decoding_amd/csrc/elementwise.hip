@@ -209,10 +209,21 @@ __device__ inline void block_partial_sums(const float* __restrict__ partial, int
 #pragma unroll
   for (int j = 0; j < 4; ++j) { sh[0][ty][tx * 4 + j] = a0[j]; sh[1][ty][tx * 4 + j] = a1[j]; }
   __syncthreads();
-  s0 = 0.0; s1 = 0.0;
-  if (threadIdx.x < 8) {
-    for (int g = 0; g < 128; ++g) { s0 += sh[0][g][threadIdx.x]; s1 += sh[1][g][threadIdx.x]; }
+  // 128 threads: (which, channel, eighth) -> 16 groups each, then a fixed shuffle tree over the eighths
+  __shared__ double res[2][8];
+  if (threadIdx.x < 128) {
+    const int part = threadIdx.x & 7, c = (threadIdx.x >> 3) & 7, which = threadIdx.x >> 6;
+    double a = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) a += sh[which][part * 16 + g][c];
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    a += __shfl_xor(a, 4);
+    if (part == 0) res[which][c] = a;
   }
+  __syncthreads();
+  s0 = 0.0; s1 = 0.0;
+  if (threadIdx.x < 8) { s0 = res[0][threadIdx.x]; s1 = res[1][threadIdx.x]; }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, double count,

@@ -61,6 +61,7 @@ class EncoderCtx:
     subj_seg: Optional[torch.Tensor] = None
     W_sa: Optional[torch.Tensor] = None
     packed_T: Dict[str, torch.Tensor] = field(default_factory=dict)
+    packed_T_ready: Optional[torch.cuda.Event] = None     # side-stream packing of packed_T has finished
 
 
 class EncoderEngine:
@@ -80,6 +81,9 @@ class EncoderEngine:
         # weight-gradient chains (wgrad_gemm -> reduce_slabs -> unpack) depend only on dy and a saved
         # activation, never on each other or on the data-gradient chain: run them on a second HIP stream
         self.wgrad_side_stream = True
+        self.pack_on_side_stream = True      # per-step operand packing runs beside the first layers, not in front
+        self.forward_pair_tiles = True       # forward k = 3 convs (nothing competes for the CU's LDS there): two
+                                             # tiles per workgroup share each weight slab — fewer LDS-DMA bytes per FLOP
         self._side = {}
 
     @property
@@ -187,9 +191,28 @@ class EncoderEngine:
 
         # ---- operand packing (fp32 master weights -> compute dtype, K-contiguous, zero padded): ONE launch
         fwd_plan, bwd_plan = self._plans(P, dev)
-        pk.update(fwd_plan.run(P))
-        if need_grad:
-            ctx.packed_T = bwd_plan.run(P)      # [tap][ci][co] operands of the data-gradient convs
+        main = torch.cuda.current_stream(dev)
+        packed_ready = None
+        if self.pack_on_side_stream:
+            side = self._side.get(str(dev))
+            if side is None:
+                side = self._side[str(dev)] = torch.cuda.Stream(device=dev)
+            ev = torch.cuda.Event()
+            ev.record(main)                      # the optimiser's update of P is on the main stream
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                pk.update(fwd_plan.run(P))
+                packed_ready = torch.cuda.Event()
+                packed_ready.record(side)
+                if need_grad:
+                    ctx.packed_T = bwd_plan.run(P)      # [tap][ci][co] operands of the data-gradient convs
+                    ctx.packed_T_ready = torch.cuda.Event()
+                    ctx.packed_T_ready.record(side)
+        else:
+            pk.update(fwd_plan.run(P))
+            if need_grad:
+                ctx.packed_T = bwd_plan.run(P)
+        k3_flags = L.CONV_PAIR_TILES if self.forward_pair_tiles else 0
 
         # ---- SubjectBlock (models.py:111-117)
         Xt = rows("Xt", d.Cp)
@@ -199,6 +222,8 @@ class EncoderEngine:
         ctx.W_sa = W_sa
         h_sa = ops.conv_gemm(Xt, Wp, rows("h_sa", d.D1p), B=B, T=T, KS=1, dil=0, alg_dims=(d.C, d.D1))
         bufs["h_sa"] = h_sa
+        if packed_ready is not None:
+            main.wait_event(packed_ready)
         h_c = ops.conv_gemm(h_sa, pk["sb_w"], rows("h_c", d.D1p), B=B, T=T, KS=1, dil=0, bias=pk["sb_b"],
                             alg_dims=(d.D1, d.D1))
         bufs["h_c"] = h_c
@@ -221,7 +246,8 @@ class EncoderEngine:
                 bnp = f"b{k}.bn{j}"
                 if training:
                     stats = torch.empty((ntile, 2, d.D2p), dtype=torch.float32, device=dev)
-                    ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, stats=stats, alg_dims=alg)
+                    ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, stats=stats, alg_dims=alg,
+                                  dbg_flags=k3_flags)
                     nt = ntile
                     if world > 1:                # one 2*Cp-float all-reduce per BatchNorm
                         stats = ops.reduce_slabs(stats).reshape(1, 2, d.D2p)
@@ -232,7 +258,7 @@ class EncoderEngine:
                                                                       want_bwd_coef=True)
                 else:
                     bcoef = None
-                    ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, alg_dims=alg)
+                    ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, alg_dims=alg, dbg_flags=k3_flags)
                     mean, rstd, scale, shift = ops.bn_finalize(None, 0, count, P[bnp + "w"], P[bnp + "b"],
                                                                P[bnp + "rm"], P[bnp + "rv"], d.D2p, False, eps, momentum)
                 ctx.bn[bnp] = (mean, rstd, bcoef)
@@ -240,7 +266,8 @@ class EncoderEngine:
                 bufs[f"b{k}.h{j}"], bufs[f"b{k}.a{j}"] = h, a
                 x = a
             w, bias = pk[f"b{k}.c2w"], pk[f"b{k}.c2b"]
-            c2 = ops.conv_gemm(x, w, rows(f"b{k}.c2", 2 * d.D2p), B=B, T=T, KS=3, dil=dil[2], bias=bias, alg_dims=(d.D2, 2 * d.D2))
+            c2 = ops.conv_gemm(x, w, rows(f"b{k}.c2", 2 * d.D2p), B=B, T=T, KS=3, dil=dil[2], bias=bias, alg_dims=(d.D2, 2 * d.D2),
+                               dbg_flags=k3_flags)
             x = ops.glu_forward(c2, rows(f"x{k + 1}", d.D2p), B, T)
             bufs[f"b{k}.c2"], bufs[f"x{k + 1}"] = c2, x
 
@@ -266,6 +293,8 @@ class EncoderEngine:
         d, dt = self.d, self.dtype
         B, T, bufs = ctx.B, ctx.T, ctx.bufs
         dev = dZt.device
+        if getattr(ctx, "packed_T_ready", None) is not None:
+            torch.cuda.current_stream(dev).wait_event(ctx.packed_T_ready)
         grads: Dict[str, torch.Tensor] = {}
         scratch = ops.reduce_scratch(max(d.Fp, 2 * d.D2p, d.F1p), dev)
         pending = []                          # (work, names) of in-flight gradient all-reduces

@@ -15,6 +15,7 @@ F32, BF16 = 0, 1
 ROW_PAD = 16
 CH_ALIGN = 64
 EPI_GELU = 1
+CONV_SINGLE_TILE, CONV_PAIR_TILES, CONV_PERSIST = 4096, 8192, 16384
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 

@@ -107,26 +107,48 @@ def gather_speech_rows(Yt_local: torch.Tensor, B: int, T: int, group, async_op: 
     return Yt, ysq, B * world, rank * B, B * world, ([w1, w2] if async_op else [])
 
 
-_prefetched = []          # [(weakref(Y), dtype, Yt, ysq, Bm, col0, Bg, works)] — at most one pending prefetch
+_prefetched = []          # [(weakref(Y), dtype, Yt, ysq, Bm, col0, Bg, works, done_event)] — at most one pending prefetch
+_prefetch_streams = {}    # device -> side stream the speech-side work runs on
+PREFETCH_ON_SIDE_STREAM = True
 
 
 def prefetch_speech(Y: torch.Tensor, dtype=None, global_negatives: bool = True):
-    """Start the speech-side work of the loss EARLY: pack Y into row layout and, under data parallelism, launch
-    the all-gather of the packed rows asynchronously on RCCL's stream.  Y does not depend on the encoder, so
-    calling this before `brain_encoder(X, ...)` hides the 1.4 GB (8 GPUs, config 3) gather behind the forward."""
+    """Start the speech-side work of the loss EARLY: pack Y into row layout, take its row norms and, under data
+    parallelism, launch the all-gather of the packed rows asynchronously on RCCL's stream.  Y does not depend on
+    the encoder, so calling this before `brain_encoder(X, ...)` hides the 1.4 GB (8 GPUs, config 3) gather behind
+    the forward.  The pack + norms (HBM-bound, ~0.2 ms at config 2) run on a side stream of their own, beside the
+    encoder's first layers instead of in front of them."""
     B, F, T = Y.shape
     dtype = dtype or torch.float32
-    Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y")
     group = _dist_group() if global_negatives else None
-    Yt, ysq, Bm, col0, Bg, works = gather_speech_rows(Yt_local, B, T, group, async_op=True)
+    done = None
+    if PREFETCH_ON_SIDE_STREAM and Y.is_cuda:
+        main = torch.cuda.current_stream(Y.device)
+        side = _prefetch_streams.get(str(Y.device))
+        if side is None:
+            side = _prefetch_streams[str(Y.device)] = torch.cuda.Stream(device=Y.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)                       # Y itself, and the previous user of the ring buffer, are on `main`
+        with torch.cuda.stream(side):
+            Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y")
+            Yt, ysq, Bm, col0, Bg, works = gather_speech_rows(Yt_local, B, T, group, async_op=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        ysq.record_stream(main)
+    else:
+        Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y")
+        Yt, ysq, Bm, col0, Bg, works = gather_speech_rows(Yt_local, B, T, group, async_op=True)
     _prefetched.clear()
-    _prefetched.append((weakref.ref(Y), dtype, Yt, ysq, Bm, col0, Bg, works))
+    _prefetched.append((weakref.ref(Y), dtype, Yt, ysq, Bm, col0, Bg, works, done))
 
 
 def _take_prefetched(Y, dtype):
-    for wy, dt, Yt, ysq, Bm, col0, Bg, works in _prefetched:
+    for wy, dt, Yt, ysq, Bm, col0, Bg, works, done in _prefetched:
         if wy() is Y and dt == dtype:
             _prefetched.clear()
+            if done is not None:
+                torch.cuda.current_stream(Yt.device).wait_event(done)
             for work in works:
                 work.wait()                     # current stream waits for RCCL's stream; the host does not block
             return Yt, ysq, Bm, col0, Bg

@@ -73,13 +73,13 @@ def test_pack_unpack_roundtrip_and_padding(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tiling", [4096, 8192])          # one tile / two tiles per workgroup
+@pytest.mark.parametrize("tiling", [4096, 8192, 16384])   # one tile / two tiles per workgroup / persistent
 @pytest.mark.parametrize("cin,cout,dil,T", [(40, 48, 1, 40), (270, 320, 2, 300), (320, 320, 16, 360),
                                             (96, 128, 8, 130), (64, 640, 4, 129)])
 def test_conv3_forward_bias_residual_stats(ops, dtype, cin, cout, dil, T, tiling):
     from speech_decoding_amd import lib as L
     g = torch.Generator().manual_seed(cin + cout + dil)
-    B = 3 if tiling == 8192 else 2                        # odd tile counts leave a half-empty workgroup
+    B = 3 if tiling != 4096 else 2                        # odd tile counts leave a half-empty workgroup
     x = q(torch.randn(B, cin, T, generator=g), dtype)
     w = q(torch.randn(cout, cin, 3, generator=g) / math.sqrt(3 * cin), dtype)
     bias = torch.randn(cout, generator=g)
@@ -171,7 +171,7 @@ def test_conv3_dgrad_and_wgrad(ops, dtype, cin, cout, dil, T, glu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tiling", [4096, 8192])
+@pytest.mark.parametrize("tiling", [4096, 8192, 16384])
 @pytest.mark.parametrize("cin,cout,dil,T", [(48, 40, 2, 70), (640, 320, 2, 300), (320, 320, 8, 360)])
 def test_conv3_bn_backward_statistics_epilogue(ops, dtype, cin, cout, dil, T, tiling):
     """conv_gemm(bn_x=...) writes its output AND the BatchNorm+GELU backward sums of the layer that output is
