@@ -59,6 +59,7 @@ class EncoderCtx:
     widx: Optional[torch.Tensor] = None
     subj_perm: Optional[torch.Tensor] = None
     subj_seg: Optional[torch.Tensor] = None
+    subj_slices: int = 1                                  # K-segments per subject in the per-subject weight gradient
     W_sa: Optional[torch.Tensor] = None
     packed_T: Dict[str, torch.Tensor] = field(default_factory=dict)
     packed_T_ready: Optional[torch.cuda.Event] = None     # side-stream packing of packed_T has finished
@@ -183,10 +184,30 @@ class EncoderEngine:
         up = ops.UPLOADER.upload                # pinned staging: no implicit host<->stream synchronisation
         ctx.widx = up(("widx", space), sidx.astype(np.int32), dev)
         if need_grad:
+            # per-subject weight gradient: samples sorted by subject, one K-segment per (slice j, subject s) in
+            # j-major order.  With many subjects one slice each is enough (the S segments already fill the GPU);
+            # with few (S = 1 in configs 1/4) every subject's samples are cut into r slices so that the launch still
+            # has ~wgrad_target_wgs workgroups, and the r slabs of a subject are summed afterwards in fixed order.
             order = np.argsort(sidx, kind="stable").astype(np.int32)
-            seg = np.searchsorted(sidx[order], np.arange(d.S + 1)).astype(np.int32)
-            ctx.subj_perm = up("subj_perm", order, dev)
+            bounds = np.searchsorted(sidx[order], np.arange(d.S + 1)).astype(np.int64)
+            tile_m = 160 if d.D1p % 160 == 0 else (128 if d.D1p % 128 == 0 else 64)
+            ntiles = (d.D1p // tile_m) * (d.D1p // (128 if d.D1p % 128 == 0 else 64))
+            r = int(max(1, min(max(1, B // max(1, d.S)), round(self.wgrad_target_wgs / max(1, ntiles * d.S)))))
+            lo, hi = bounds[:-1], bounds[1:]
+            cuts = [lo + ((hi - lo) * j) // r for j in range(r + 1)]          # r + 1 arrays of S cut points
+            seg = np.empty(r * d.S + 1, dtype=np.int32)
+            perm_parts, pos = [], 0
+            for j in range(r):
+                for sbj in range(d.S):
+                    a_, b_ = int(cuts[j][sbj]), int(cuts[j + 1][sbj])
+                    seg[j * d.S + sbj] = pos
+                    perm_parts.append(order[a_:b_])
+                    pos += b_ - a_
+            seg[r * d.S] = pos
+            perm = np.concatenate(perm_parts).astype(np.int32) if perm_parts else order
+            ctx.subj_perm = up("subj_perm", perm, dev)
             ctx.subj_seg = up("subj_seg", seg, dev)
+            ctx.subj_slices = r
         ctx.mask = mask
 
         # ---- operand packing (fp32 master weights -> compute dtype, K-contiguous, zero padded): ONE launch
@@ -429,9 +450,14 @@ class EncoderEngine:
 
         # ---- SubjectBlock
         dhs = dx                                            # (rows, D1p)
-        grads["subj_w"] = on_side(lambda: ops.unpack_conv_wgrad(
-            ops.wgrad_gemm(dhs, bufs["h_c"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg, nseg=d.S),
-            d.S, d.D1, d.D1, 1, d.D1p, d.D1p))
+        def subj_wgrad():
+            r = ctx.subj_slices
+            slabs = ops.wgrad_gemm(dhs, bufs["h_c"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg,
+                                   nseg=r * d.S)                        # (r*S, 1, D1p, D1p), slice-major
+            if r > 1:
+                slabs = ops.reduce_slabs(slabs.view(r, -1)).view(d.S, 1, d.D1p, d.D1p)
+            return ops.unpack_conv_wgrad(slabs, d.S, d.D1, d.D1, 1, d.D1p, d.D1p)
+        grads["subj_w"] = on_side(subj_wgrad)
         dh_c, _ = dgrad(dhs, "subj_w", P["subj_w"], d.D1p, d.D1p, tmp("dh_c", d.D1p), 1, 0, widx=ctx.widx)
         grads["sb_w"] = wgrad(dh_c, bufs["h_sa"], 1, 0, d.D1, d.D1)
         grads["sb_b"] = ops.unpack_vector(ops.colsum(dh_c, B, T, scratch), d.D1)
