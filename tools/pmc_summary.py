@@ -7,7 +7,7 @@ Corrections follow MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx95
 import collections, csv, glob, json, sys
 
 def load(d):
-    f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
+    f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
