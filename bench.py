@@ -182,7 +182,7 @@ def main():
 
     cnt = torch.cat(ranks_acc[-3:]).float()
     top10 = float((cnt < 10).float().mean())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         out = {

@@ -12,8 +12,6 @@
 // all KS taps and streams its segment's samples in 64-row chunks; the three taps read the same staged x
 // image at row offsets tap*dil.  Segments make the K split explicit: per-subject weight gradients use one
 // segment per subject (final result, no reduction), shared weights use ~CU-count segments + reduce_slabs.
-#include <stdlib.h>
-
 #include "sd_common.h"
 
 namespace sda {
@@ -297,33 +295,12 @@ static int launch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
   return check_launch("wgrad_gemm");
 }
 
-static int wgrad_variant() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SDA_WGRAD_VARIANT"); v = e ? atoi(e) : 0; }
-  return v;
-}
-
 template <typename E, int TILE_M>
 static int dispatch_wgrad_m(const sda_wgrad_args& a, hipStream_t st) {
-  const int v = wgrad_variant();
-  if (a.KS == 3) {
-    if constexpr (TILE_M == 160) {
-      if (v == 1) return launch_wgrad<E, TILE_M, 3, 64, 2, 3>(a, st);
-      if (v == 2) return launch_wgrad<E, TILE_M, 3, 64, 1, 4>(a, st);
-      if (v == 3) return launch_wgrad<E, TILE_M, 3, 64, 1, 3>(a, st);
-      if (v == 4) return launch_wgrad<E, TILE_M, 3, 64, 2, 4>(a, st);
-    }
-    return launch_wgrad<E, TILE_M, 3, 64>(a, st);
-  }
-  if (a.Cin_p % 128 == 0) {
-    if constexpr (TILE_M == 128) {
-      if (v == 1) return launch_wgrad<E, TILE_M, 1, 128, 2, 3>(a, st);
-      if (v == 2) return launch_wgrad<E, TILE_M, 1, 128, 1, 4>(a, st);
-      if (v == 3) return launch_wgrad<E, TILE_M, 1, 128, 1, 3>(a, st);
-      if (v == 4) return launch_wgrad<E, TILE_M, 1, 128, 2, 4>(a, st);
-    }
-    return launch_wgrad<E, TILE_M, 1, 128>(a, st);
-  }
+  // KM = 2 K-steps per chunk, NS = 2 stages: deeper pipelines (NS = 3, 4) and one-step chunks were measured
+  // slower at one and at two workgroups per CU
+  if (a.KS == 3) return launch_wgrad<E, TILE_M, 3, 64>(a, st);
+  if (a.Cin_p % 128 == 0) return launch_wgrad<E, TILE_M, 1, 128>(a, st);
   return launch_wgrad<E, TILE_M, 1, 64>(a, st);
 }
 

@@ -78,7 +78,7 @@ class EncoderEngine:
         self._gen = 0
         self.reuse_workspace = True
         self.fuse_bn_backward_stats = True   # BatchNorm-backward sums in the data-gradient conv's epilogue
-        self.wgrad_target_wgs = int(__import__('os').environ.get('SDA_WGRAD_WGS', 256))          # workgroups per weight-gradient launch (split over sample segments)
+        self.wgrad_target_wgs = 256          # workgroups per weight-gradient launch (split over sample segments)
         # weight-gradient chains (wgrad_gemm -> reduce_slabs -> unpack) depend only on dy and a saved
         # activation, never on each other or on the data-gradient chain: run them on a second HIP stream
         self.wgrad_side_stream = True
@@ -188,23 +188,10 @@ class EncoderEngine:
             # j-major order.  With many subjects one slice each is enough (the S segments already fill the GPU);
             # with few (S = 1 in configs 1/4) every subject's samples are cut into r slices so that the launch still
             # has ~wgrad_target_wgs workgroups, and the r slabs of a subject are summed afterwards in fixed order.
-            order = np.argsort(sidx, kind="stable").astype(np.int32)
-            bounds = np.searchsorted(sidx[order], np.arange(d.S + 1)).astype(np.int64)
             tile_m = 160 if d.D1p % 160 == 0 else (128 if d.D1p % 128 == 0 else 64)
             ntiles = (d.D1p // tile_m) * (d.D1p // (128 if d.D1p % 128 == 0 else 64))
             r = int(max(1, min(max(1, B // max(1, d.S)), round(self.wgrad_target_wgs / max(1, ntiles * d.S)))))
-            lo, hi = bounds[:-1], bounds[1:]
-            cuts = [lo + ((hi - lo) * j) // r for j in range(r + 1)]          # r + 1 arrays of S cut points
-            seg = np.empty(r * d.S + 1, dtype=np.int32)
-            perm_parts, pos = [], 0
-            for j in range(r):
-                for sbj in range(d.S):
-                    a_, b_ = int(cuts[j][sbj]), int(cuts[j + 1][sbj])
-                    seg[j * d.S + sbj] = pos
-                    perm_parts.append(order[a_:b_])
-                    pos += b_ - a_
-            seg[r * d.S] = pos
-            perm = np.concatenate(perm_parts).astype(np.int32) if perm_parts else order
+            perm, seg = subject_segments(sidx, d.S, r)
             ctx.subj_perm = up("subj_perm", perm, dev)
             ctx.subj_seg = up("subj_seg", seg, dev)
             ctx.subj_slices = r
@@ -268,7 +255,7 @@ class EncoderEngine:
                 if training:
                     stats = torch.empty((ntile, 2, d.D2p), dtype=torch.float32, device=dev)
                     ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, stats=stats, alg_dims=alg,
-                                  dbg_flags=k3_flags)
+                                  flags=k3_flags)
                     nt = ntile
                     if world > 1:                # one 2*Cp-float all-reduce per BatchNorm
                         stats = ops.reduce_slabs(stats).reshape(1, 2, d.D2p)
@@ -279,7 +266,7 @@ class EncoderEngine:
                                                                       want_bwd_coef=True)
                 else:
                     bcoef = None
-                    ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, alg_dims=alg, dbg_flags=k3_flags)
+                    ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, alg_dims=alg, flags=k3_flags)
                     mean, rstd, scale, shift = ops.bn_finalize(None, 0, count, P[bnp + "w"], P[bnp + "b"],
                                                                P[bnp + "rm"], P[bnp + "rv"], d.D2p, False, eps, momentum)
                 ctx.bn[bnp] = (mean, rstd, bcoef)
@@ -288,7 +275,7 @@ class EncoderEngine:
                 x = a
             w, bias = pk[f"b{k}.c2w"], pk[f"b{k}.c2b"]
             c2 = ops.conv_gemm(x, w, rows(f"b{k}.c2", 2 * d.D2p), B=B, T=T, KS=3, dil=dil[2], bias=bias, alg_dims=(d.D2, 2 * d.D2),
-                               dbg_flags=k3_flags)
+                               flags=k3_flags)
             x = ops.glu_forward(c2, rows(f"x{k + 1}", d.D2p), B, T)
             bufs[f"b{k}.c2"], bufs[f"x{k + 1}"] = c2, x
 
@@ -472,6 +459,28 @@ class EncoderEngine:
         for work in pending:
             work.wait()                       # makes the current stream wait for RCCL's; no host sync
         return grads
+
+
+def subject_segments(sidx: np.ndarray, S: int, r: int):
+    """K-segments of the per-subject weight gradient: samples sorted by subject (stable), each subject's run cut
+    into `r` nearly equal slices, segments listed slice-major (segment j*S + s = slice j of subject s) so that the
+    r slabs of one subject are `r` equally strided blocks for the ordered slab sum.
+    Returns (perm int32 [B], seg_start int32 [r*S + 1])."""
+    order = np.argsort(sidx, kind="stable").astype(np.int32)
+    bounds = np.searchsorted(sidx[order], np.arange(S + 1)).astype(np.int64)
+    lo, hi = bounds[:-1], bounds[1:]
+    cuts = [lo + ((hi - lo) * j) // r for j in range(r + 1)]              # r + 1 arrays of S cut points
+    seg = np.empty(r * S + 1, dtype=np.int32)
+    parts, pos = [], 0
+    for j in range(r):
+        for s in range(S):
+            a_, b_ = int(cuts[j][s]), int(cuts[j + 1][s])
+            seg[j * S + s] = pos
+            parts.append(order[a_:b_])
+            pos += b_ - a_
+    seg[r * S] = pos
+    perm = np.concatenate(parts).astype(np.int32) if parts else order
+    return perm, seg
 
 
 # ----------------------------------------------------------------------------------------------- loss

@@ -217,7 +217,6 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
-_ENV_CONV_FLAGS = int(__import__("os").environ.get("SDA_CONV_FLAGS", "0"))     # experiments: 8192 = paired tiles
 
 
 def conv_tile_co(Cout_p: int) -> int:
@@ -225,7 +224,7 @@ def conv_tile_co(Cout_p: int) -> int:
 
 
 def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=None, stats=None, gelu=False,
-              alg_dims=None, dbg_flags=0, bn_x=None, bn_coef=None):
+              alg_dims=None, flags=0, bn_x=None, bn_coef=None):
     """RL conv: x (rows, Cin_p), w (nW, KS, Cout_p, Cin_p) packed, y (rows, Cout_p).
     alg_dims = (Cin, Cout) unpadded, only used to count algorithmic FLOPs when the timer is on."""
     _need_cuda(x, w, y)
@@ -243,7 +242,7 @@ def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=N
     if x.shape[0] < L.rows_alloc(B, T) or y.shape[0] < L.rows_alloc(B, T):
         raise L.SdaError("conv_gemm: RL buffers too small for (B, T)")
     a.w_rows_limit, a.ksplit = y.shape[1], 1
-    a.flags, a.dtype = (L.EPI_GELU if gelu else 0) | dbg_flags | _ENV_CONV_FLAGS, dt_code(x.dtype)
+    a.flags, a.dtype = (L.EPI_GELU if gelu else 0) | flags, dt_code(x.dtype)
     if TIMER is not None:
         cin, cout = alg_dims if alg_dims is not None else (x.shape[1], y.shape[1])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -107,3 +107,25 @@ def test_uniform_and_subject_segments():
         assert torch.equal(perm, torch.arange(B, dtype=torch.int32))
     d = eng.d
     assert (d.Cp, d.D1p, d.D2p, d.F1p, d.Fp) == (256, 320, 320, 640, 1024)
+
+
+@pytest.mark.parametrize("S,r,B", [(27, 1, 256), (1, 26, 512), (3, 2, 8), (4, 5, 13), (2, 3, 2)])
+def test_subject_segments_partition_the_batch_slice_major(S, r, B):
+    """Per-subject weight-gradient segments: every sample appears once, segment j*S + s holds only subject s,
+    the r slices of a subject cover it in order and differ in size by at most one."""
+    from speech_decoding_amd.engine import subject_segments
+    rng = np.random.default_rng(S * 100 + r)
+    sidx = rng.integers(0, S, size=B).astype(np.int64)
+    if S > 2:
+        sidx[sidx == 1] = 0                                  # a subject that is absent from the batch
+    perm, seg = subject_segments(sidx, S, r)
+    assert perm.dtype == np.int32 and seg.dtype == np.int32 and seg.shape == (r * S + 1,)
+    assert sorted(perm.tolist()) == list(range(B)) and seg[0] == 0 and seg[-1] == B and (np.diff(seg) >= 0).all()
+    for s in range(S):
+        members = [perm[seg[j * S + s]: seg[j * S + s + 1]] for j in range(r)]
+        for m in members:
+            assert (sidx[m] == s).all()
+        sizes = [len(m) for m in members]
+        assert sum(sizes) == int((sidx == s).sum()) and max(sizes) - min(sizes) <= 1
+        joined = np.concatenate(members) if members else np.empty(0, dtype=np.int32)
+        assert (np.diff(joined) > 0).all()                   # stable: ascending sample index within a subject

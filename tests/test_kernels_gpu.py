@@ -93,7 +93,7 @@ def test_conv3_forward_bias_residual_stats(ops, dtype, cin, cout, dil, T, tiling
     yb = ops.new_rows(B, T, Cout_p, dtype, DEV)
     stats = torch.zeros((B * ops.n_t_tiles(T), 2, Cout_p), device=DEV)
     ops.conv_gemm(xb, wp, yb, B=B, T=T, KS=3, dil=dil, bias=ops.pack_vector(bias.to(DEV), Cout_p),
-                  res=xb if use_res else None, stats=stats, dbg_flags=tiling)
+                  res=xb if use_res else None, stats=stats, flags=tiling)
     got = from_rows(ops, yb, B, cout, T)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), **tol(dtype, 3 * cin))
     # pad rows / channels of the output stay zero
@@ -198,9 +198,9 @@ def test_conv3_bn_backward_statistics_epilogue(ops, dtype, cin, cout, dil, T, ti
     assert float(coef[:, cout:].abs().max()) == 0.0 if Cout_p > cout else True
     out = ops.new_rows(B, T, Cout_p, dtype, DEV)
     st = torch.full((B * ops.n_t_tiles(T), 2, Cout_p), float("nan"), device=DEV)
-    ops.conv_gemm(dyb, wp, out, B=B, T=T, KS=3, dil=dil, res=res, stats=st, bn_x=h, bn_coef=coef, dbg_flags=tiling)
+    ops.conv_gemm(dyb, wp, out, B=B, T=T, KS=3, dil=dil, res=res, stats=st, bn_x=h, bn_coef=coef, flags=tiling)
     plain = ops.new_rows(B, T, Cout_p, dtype, DEV)
-    ops.conv_gemm(dyb, wp, plain, B=B, T=T, KS=3, dil=dil, res=res, dbg_flags=tiling)
+    ops.conv_gemm(dyb, wp, plain, B=B, T=T, KS=3, dil=dil, res=res, flags=tiling)
     assert torch.equal(out, plain)                                   # the output itself is unchanged by the mode
     dx1, dx2 = ops.new_rows(B, T, Cout_p, dtype, DEV), ops.new_rows(B, T, Cout_p, dtype, DEV)
     dg_ref, db_ref = ops.bn_gelu_backward(out, h, mean, rstd, gamma, beta, dx1, B, T, ops.reduce_scratch(Cout_p, DEV))

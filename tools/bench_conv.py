@@ -27,11 +27,11 @@ def main():
             res = x if cin == cout else None
             fl = 2.0 * B * T * KS * cin * cout
             for name, kw in [("full", dict(bias=bias, res=res, stats=stats)), ("plain", dict()),
-                             ("no_epi", dict(dbg_flags=256)), ("no_main", dict(bias=bias, res=res, stats=stats, dbg_flags=512)),
-                             ("neither", dict(dbg_flags=768)), ("pair_full", dict(bias=bias, res=res, stats=stats, dbg_flags=8192)),
-                             ("persist", dict(bias=bias, res=res, stats=stats, dbg_flags=16384)), ("persist_plain", dict(dbg_flags=16384)),
-                             ("persist_bias", dict(bias=bias, dbg_flags=16384)), ("persist_res", dict(res=res, dbg_flags=16384)),
-                             ("persist_stats", dict(stats=stats, dbg_flags=16384)), ("persist_nostore", dict(dbg_flags=16384 | 256))]:
+                             ("no_epi", dict(flags=256)), ("no_main", dict(bias=bias, res=res, stats=stats, flags=512)),
+                             ("neither", dict(flags=768)), ("pair_full", dict(bias=bias, res=res, stats=stats, flags=8192)),
+                             ("persist", dict(bias=bias, res=res, stats=stats, flags=16384)), ("persist_plain", dict(flags=16384)),
+                             ("persist_bias", dict(bias=bias, flags=16384)), ("persist_res", dict(res=res, flags=16384)),
+                             ("persist_stats", dict(stats=stats, flags=16384)), ("persist_nostore", dict(flags=16384 | 256))]:
                 us = timeit(lambda: ops.conv_gemm(x, wp, y, B=B, T=T, KS=KS, dil=dil, **kw))
                 print(f"conv {str(dtype)[6:]:8s} {cin}->{cout} k{KS} {name:8s} {us:8.1f} us  {fl/us/1e6:7.1f} TF", flush=True)
             if KS == 3 or cout == 1024:

@@ -20,7 +20,7 @@ def main():
     res = x if cin == cout else None
     if what == "conv":
         for _ in range(n):
-            ops.conv_gemm(x, wp, y, B=B, T=T, KS=KS, dil=dil, bias=bias, res=res, stats=stats, dbg_flags=flags)
+            ops.conv_gemm(x, wp, y, B=B, T=T, KS=KS, dil=dil, bias=bias, res=res, stats=stats, flags=flags)
     else:
         dy = ops.new_rows(B, T, cout, dtype, dev); dy.normal_()
         nseg = int(os.environ.get("NSEG", 24))
