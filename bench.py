@@ -106,14 +106,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from oracle import brain_oracle as O           # data generator + cpu_baseline leg only
     from speech_decoding_amd import Classifier, BrainEncoder, CLIPLoss, load_config, ops
+    from speech_decoding_amd.layout import synthetic_positions
     from speech_decoding_amd import loss as sda_loss
     from speech_decoding_amd.distributed import allreduce_gradients, broadcast_parameters
 
     torch.manual_seed(0)
     np.random.seed(0)
-    loc = O.synthetic_positions(C, seed=0)
+    loc = synthetic_positions(C, seed=0)        # (the oracle is imported by the cpu_baseline leg only)
     cfg = load_config(overrides=[f"num_subjects={S}", f"compute_dtype={a.dtype}", "dataset=Gwilliams2022"])
     cfg["sensor_positions"] = loc.numpy()
     with warnings.catch_warnings():

@@ -23,6 +23,12 @@ def normalise(raw_xy) -> torch.Tensor:
     return torch.from_numpy((out * 0.8 + 0.1).astype(np.float32))
 
 
+def synthetic_positions(num_channels: int, seed: int = 0) -> torch.Tensor:
+    """Seeded stand-in sensor table (uniform in the unit square, then the reference's normalisation) for
+    benchmarks and runs without MNE / the dataset on disk."""
+    return normalise(np.random.RandomState(seed).rand(num_channels, 2))
+
+
 def _opt(args, key, default=None):
     if isinstance(args, dict):
         return args.get(key, default)
@@ -61,4 +67,4 @@ def ch_locations_2d(args) -> torch.Tensor:
         n = int(_opt(args, "num_channels", DEFAULT_CHANNELS[dataset]))
         warnings.warn(f"MNE sensor layout unavailable; using a seeded synthetic {n}-sensor layout "
                       "(pass args.sensor_positions for real geometry)")
-        return normalise(np.random.RandomState(0).rand(n, 2))
+        return synthetic_positions(n, 0)

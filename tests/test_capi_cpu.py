@@ -103,3 +103,22 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_oracle_is_imported_only_by_the_checkers():
+    """Outside tests/: only __graft_entry__.smoke() and bench.py's cpu_baseline() may import the oracle."""
+    import re
+    offenders = []
+    for rel in ["train.py"] + [os.path.join("tools", f) for f in os.listdir(os.path.join(ROOT, "tools")) if f.endswith(".py")]:
+        if re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(ROOT, rel)).read(), re.M):
+            offenders.append(rel)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "speech_decoding")):
+        for f in files:
+            if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(dirpath, f)).read(), re.M):
+                offenders.append(f)
+    assert not offenders, offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    hits = [m.start() for m in re.finditer(r"^\s*(from|import)\s+oracle", bench, re.M)]
+    assert len(hits) == 1
+    head = bench[: hits[0]]
+    assert head.rfind("def cpu_baseline") > head.rfind("\ndef main"), "bench.py: oracle import outside cpu_baseline()"

@@ -2,14 +2,14 @@
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import brain_oracle as O
+from speech_decoding_amd.layout import synthetic_positions
 from speech_decoding_amd import BrainEncoder, CLIPLoss, load_config
 from speech_decoding_amd.optim import FusedAdam
 
 def run(name, C, S, T, B, F=1024, dtype="bf16", steps=8):
     dev = "cuda:0"
     cfg = load_config(overrides=[f"num_subjects={S}", f"compute_dtype={dtype}"])
-    cfg["sensor_positions"] = O.synthetic_positions(C, 0).numpy()
+    cfg["sensor_positions"] = synthetic_positions(C, 0).numpy()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         enc = BrainEncoder(cfg).to(dev).train()

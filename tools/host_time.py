@@ -2,13 +2,13 @@
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import brain_oracle as O
+from speech_decoding_amd.layout import synthetic_positions
 from speech_decoding_amd import BrainEncoder, CLIPLoss, load_config
 from speech_decoding_amd import loss as sda_loss
 C, S, T, F = 208, 27, 360, 1024
 dev = "cuda:0"
 cfg = load_config(overrides=[f"num_subjects={S}", "compute_dtype=bf16"])
-cfg["sensor_positions"] = O.synthetic_positions(C, 0).numpy()
+cfg["sensor_positions"] = synthetic_positions(C, 0).numpy()
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     enc = BrainEncoder(cfg).to(dev).train()
