@@ -67,14 +67,25 @@ def shard_range(n: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
-def merge_row_softmax_stats(row_max: torch.Tensor, row_sum: torch.Tensor, group=None):
+def merge_row_softmax_stats(row_max: torch.Tensor, row_sum: torch.Tensor, group=None, diag: torch.Tensor = None):
     """Each rank holds, for every GLOBAL speech row, (max, sum exp(l - max)) over ITS OWN block of brain
-    columns.  Returns the row-wise log-sum-exp over all columns of all ranks (2 small all-reduces):
-        M = max_r m_r ;  S = sum_r s_r * exp(m_r - M) ;  lse = M + log S."""
+    columns.  Returns the row-wise log-sum-exp over all columns of all ranks:
+        M = max_r m_r ;  S = sum_r s_r * exp(m_r - M) ;  lse = M + log S.
+    ONE collective: the (max, sum[, diag]) rows of every rank are all-gathered (3 * B_global floats per rank)
+    and merged locally in rank order — the small collectives of a step are latency-bound, so they are packed.
+    With `diag` (each rank's positives' logits, zero where the positive lives elsewhere) returns
+    (lse, diag summed over ranks)."""
     if group is not None and dist.is_initialized() and dist.get_world_size(group) > 1:     # None = stay local
-        gmax = row_max.clone()
-        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
-        row_sum = row_sum * torch.exp(row_max - gmax)
-        dist.all_reduce(row_sum, op=dist.ReduceOp.SUM, group=group)
+        world = dist.get_world_size(group)
+        parts = [row_max, row_sum] + ([diag] if diag is not None else [])
+        mine = torch.stack([p.to(torch.float32) for p in parts]).contiguous()             # (k, Bg)
+        flat = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=torch.float32, device=mine.device)
+        dist.all_gather_into_tensor(flat, mine, group=group)          # concatenation along dim 0, rank-major
+        allp = flat.view(world, mine.shape[0], mine.shape[1])
+        gmax = allp[:, 0].max(dim=0).values
+        row_sum = (allp[:, 1] * torch.exp(allp[:, 0] - gmax)).sum(dim=0)
         row_max = gmax
-    return row_max + torch.log(row_sum)
+        if diag is not None:
+            diag = allp[:, 2].sum(dim=0)
+    lse = row_max + torch.log(row_sum)
+    return lse if diag is None else (lse, diag)

@@ -512,9 +512,7 @@ def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: 
     S = ops.matmul_nt_splitk(Yt, Zt, Bm, Bn, row_elems, row_elems)
     logits, row_max, row_sum, col_lse, diag = ops.clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0)
     from .distributed import merge_row_softmax_stats
-    if dist_group is not None and dist.get_world_size(dist_group) > 1:
-        dist.all_reduce(diag, op=dist.ReduceOp.SUM, group=dist_group)     # zero where not owned
-    row_lse = merge_row_softmax_stats(row_max, row_sum, dist_group)
+    row_lse, diag = merge_row_softmax_stats(row_max, row_sum, dist_group, diag=diag)   # diag: zero where not owned
     Bg = B_global if B_global is not None else Bm
     inv_norm = 1.0 / (2.0 * Bg) if reduction == "mean" else 0.5
     G, rscale, scalars = ops.clip_grad(logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, Yt.dtype)

@@ -172,8 +172,11 @@ class _ClipFn(torch.autograd.Function):
         loss, logits, cnt, cctx = E.clip_forward(Yt, Zt, temp.detach(), Bm=Bm, Bn=B, T=T, col0=col0,
                                                  reduction=module.reduction, B_global=Bg, dist_group=group, ysq=ysq)
         if group is not None:
-            dist.all_reduce(cnt, group=group)
-            dist.all_reduce(loss, group=group)          # report the global loss; backward uses the local share
+            # one collective for both: the rank counts (exact in fp32) and the loss share -> global loss for
+            # reporting (backward uses the local share)
+            both = torch.cat([cnt.to(torch.float32), loss.reshape(1)])
+            dist.all_reduce(both, group=group)
+            cnt, loss = both[:-1].round().to(torch.int32), both[-1:]
         ctx.cctx, ctx.shape, ctx.dtype, ctx.group = cctx, (B, F, T), dtype, group
         ctx.z_requires_grad = Z.requires_grad
         _cache_ranks(Y, Z, cnt[col0: col0 + B])

@@ -71,7 +71,11 @@ def _clip_shares(rank, world):
     blk = logits[:, lo:hi]                                           # this rank's columns
     row_max = blk.max(dim=1).values
     row_sum = torch.exp(blk - row_max[:, None]).sum(dim=1)
-    row_lse = merge_row_softmax_stats(row_max, row_sum, dist.group.WORLD)
+    owned = torch.zeros(Bg)
+    owned[lo:hi] = blk[lo:hi].diag()                                 # positives whose column lives on this rank
+    row_lse, gdiag = merge_row_softmax_stats(row_max, row_sum, dist.group.WORLD, diag=owned)
+    assert torch.allclose(gdiag, logits.diag(), atol=1e-6)           # packed into the same collective
+    assert torch.allclose(row_lse, merge_row_softmax_stats(row_max, row_sum, dist.group.WORLD), atol=1e-6)
     col_lse = torch.logsumexp(blk, dim=0)
     diag = blk[lo:hi].diag()
     share = ((row_lse[lo:hi] - diag) + (col_lse - diag)).sum() / (2 * Bg)
