@@ -166,8 +166,17 @@ __global__ void reduce_unpack_wgrad_kernel(const float* __restrict__ slabs, int 
     const int co = q % Cout; q /= Cout;
     const int tap = (int)q;
     const size_t src = ((size_t)tap * Cout_p + glu_map(co, half, half_p)) * Cin_p + ci;
+    // 8 independent loads in flight, then added in slab order (the sum order does not depend on the batching)
     float sum = 0.f;
-    for (int k = 0; k < nslabs; ++k) sum += slabs[(size_t)k * slab + src];
+    int k = 0;
+    for (; k + 8 <= nslabs; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = slabs[(size_t)(k + j) * slab + src];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[j];
+    }
+    for (; k < nslabs; ++k) sum += slabs[(size_t)k * slab + src];
     dst[((size_t)co * Cin + ci) * KS + tap] = sum;
   }
 }
@@ -546,7 +555,15 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const E* __restrict__ u, 
 __global__ void reduce_slabs_kernel(const float* __restrict__ src, float* __restrict__ dst, int nslabs, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int k = 0; k < nslabs; ++k) s += src[(size_t)k * n + i];
+    int k = 0;
+    for (; k + 8 <= nslabs; k += 8) {                     // 8 loads in flight; added in slab order
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(k + j) * n + i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; k < nslabs; ++k) s += src[(size_t)k * n + i];
     dst[i] = s;
   }
 }
