@@ -206,6 +206,15 @@ int sda_sa_weights_forward(const float* z, const float* cos_t, const float* sin_
                            float* W, void* Wp, float* scratch /* sda_sa_scratch_floats(D1, K2, C) */, int D1, int K2,
                            int C, int D1p, int Cp, int dtype, void* stream);
 int sda_sa_scratch_floats(int D1, int K2, int C);
+/* The same weight build with its two contractions on the matrix cores (sda_conv_gemm in split-K matrix mode, fp32):
+ * forward  a (D1 x C, pitch a_pitch) = [Re z | Im z] . [cos | sin]^T, then sda_sa_softmax_pack = softmax over sensors,
+ *          dropout mask, W fp32 and the packed operand Wp (as sda_sa_weights_forward);
+ * backward sda_sa_softmax_backward: da = W (dWd*mask - <dWd*mask, W>) (D1 x da_pitch, padding zeroed), then
+ *          dz = da . [cos ; sin] by the same GEMM. */
+int sda_sa_softmax_pack(const float* a, int a_pitch, const float* mask, float* W, void* Wp, int D1, int C, int D1p,
+                        int Cp, int dtype, void* stream);
+int sda_sa_softmax_backward(const float* dWd, int dwd_pitch, const float* W, const float* mask, float* da,
+                            int da_pitch, int D1, int C, void* stream);
 /* dWd fp32 [D1p][Cp] (from sda_wgrad_gemm) -> dz complex64 interleaved [D1][K2].
  * cosT/sinT are the transposed tables [C][K2] (constant buffers, transposed once by the host). */
 int sda_sa_weights_backward(const float* dWd, const float* W, const float* mask, const float* cosT,

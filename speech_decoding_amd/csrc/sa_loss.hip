@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void sa_fwd_partial_kernel(const float* __rest
     float acc[SA_R];
 #pragma unroll
     for (int r = 0; r < SA_R; ++r) acc[r] = 0.f;
+#pragma unroll 8                                       // eight table rows in flight per thread
     for (int m = 0; m < mm; ++m) {
       const float cv = cos_t[(size_t)(m0 + m) * C + c], sv = sin_t[(size_t)(m0 + m) * C + c];
 #pragma unroll
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void sa_fwd_partial_kernel(const float* __rest
 }
 
 template <typename E>
-__global__ __launch_bounds__(256) void sa_fwd_final_kernel(const float* __restrict__ part, int nchunk,
+__global__ __launch_bounds__(256) void sa_fwd_final_kernel(const float* __restrict__ part, int nchunk, int ppitch,
                                                            const float* __restrict__ mask, float* __restrict__ W,
                                                            E* __restrict__ Wp, int D1, int C, int Cp) {
   __shared__ float sh[4];
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void sa_fwd_final_kernel(const float* __restri
     const int c = tid + k * 256;
     a[k] = 0.f;
     if (c < C) {
-      for (int j = 0; j < nchunk; ++j) a[k] += part[((size_t)j * D1 + o) * C + c];
+      for (int j = 0; j < nchunk; ++j) a[k] += part[((size_t)j * D1 + o) * ppitch + c];
       mx = fmaxf(mx, a[k]);
     }
   }
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void sa_weights_bwd_kernel(const float* __rest
   float sr[SA_R], si[SA_R];
 #pragma unroll
   for (int r = 0; r < SA_R; ++r) { sr[r] = 0.f; si[r] = 0.f; }
+#pragma unroll 8
   for (int c = 0; c < C; ++c) {
     const float cv = cosT[(size_t)c * K2 + m], sv = sinT[(size_t)c * K2 + m];
 #pragma unroll
@@ -135,6 +137,19 @@ __global__ __launch_bounds__(256) void sa_weights_bwd_kernel(const float* __rest
       dz[((size_t)(o0 + r) * K2 + m) * 2 + 0] = sr[r];
       dz[((size_t)(o0 + r) * K2 + m) * 2 + 1] = si[r];
     }
+}
+
+// softmax backward only: da[o][c] = W (dW*mask - <dW*mask, W>), one block per row; padded columns of da are zeroed
+__global__ __launch_bounds__(256) void sa_softmax_bwd_kernel(const float* __restrict__ dWd, int dpitch,
+                                                             const float* __restrict__ W, const float* __restrict__ mask,
+                                                             float* __restrict__ da, int apitch, int D1, int C) {
+  __shared__ float sh[4];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  float dot = 0.f;
+  for (int c = tid; c < C; c += 256) dot += dWd[(size_t)o * dpitch + c] * (mask ? mask[c] : 1.f) * W[(size_t)o * C + c];
+  dot = block_sum(dot, sh);
+  for (int c = tid; c < apitch; c += 256)
+    da[(size_t)o * apitch + c] = c < C ? W[(size_t)o * C + c] * (dWd[(size_t)o * dpitch + c] * (mask ? mask[c] : 1.f) - dot) : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------- loss tail
@@ -243,11 +258,34 @@ extern "C" int sda_sa_weights_forward(const float* z, const float* cos_t, const 
   const int nchunk = (K2 + SA_MC - 1) / SA_MC;
   hipLaunchKernelGGL(sa_fwd_partial_kernel, dim3((D1 + SA_R - 1) / SA_R, nchunk), dim3(256), 0, st, z, cos_t, sin_t, scratch, D1, K2, C);
   if (dtype == SDA_F32)
-    hipLaunchKernelGGL(sa_fwd_final_kernel<float>, dim3(D1p), dim3(256), 0, st, scratch, nchunk, mask, W, (float*)Wp, D1, C, Cp);
+    hipLaunchKernelGGL(sa_fwd_final_kernel<float>, dim3(D1p), dim3(256), 0, st, scratch, nchunk, C, mask, W, (float*)Wp, D1, C, Cp);
   else if (dtype == SDA_BF16)
-    hipLaunchKernelGGL(sa_fwd_final_kernel<uint16_t>, dim3(D1p), dim3(256), 0, st, scratch, nchunk, mask, W, (uint16_t*)Wp, D1, C, Cp);
+    hipLaunchKernelGGL(sa_fwd_final_kernel<uint16_t>, dim3(D1p), dim3(256), 0, st, scratch, nchunk, C, mask, W, (uint16_t*)Wp, D1, C, Cp);
   else { set_error("sa_weights_forward: unknown dtype"); return -1; }
   return check_launch("sa_weights_forward");
+}
+
+/* The two GEMMs of SpatialAttention's weight build can also run on the matrix cores (sda_conv_gemm, split-K
+ * matrix mode, fp32): a = [Re z | Im z] (D1 x 2K2) . [cos | sin]^T, and dz = da . [cos ; sin] in backward.  These two
+ * entry points are the non-GEMM halves: softmax over sensors + mask + operand packing, and the softmax backward. */
+extern "C" int sda_sa_softmax_pack(const float* a, int a_pitch, const float* mask, float* W, void* Wp, int D1, int C,
+                                   int D1p, int Cp, int dtype, void* stream) {
+  if (!a || !W || !Wp || C > 512 || C > Cp || D1 > D1p || a_pitch < C) { set_error("sa_softmax_pack: bad arguments (C <= 512)"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SDA_F32)
+    hipLaunchKernelGGL(sa_fwd_final_kernel<float>, dim3(D1p), dim3(256), 0, st, a, 1, a_pitch, mask, W, (float*)Wp, D1, C, Cp);
+  else if (dtype == SDA_BF16)
+    hipLaunchKernelGGL(sa_fwd_final_kernel<uint16_t>, dim3(D1p), dim3(256), 0, st, a, 1, a_pitch, mask, W, (uint16_t*)Wp, D1, C, Cp);
+  else { set_error("sa_softmax_pack: unknown dtype"); return -1; }
+  return check_launch("sa_softmax_pack");
+}
+
+extern "C" int sda_sa_softmax_backward(const float* dWd, int dwd_pitch, const float* W, const float* mask, float* da,
+                                       int da_pitch, int D1, int C, void* stream) {
+  if (!dWd || !W || !da || dwd_pitch < C || da_pitch < C || D1 < 1) { set_error("sa_softmax_backward: bad arguments"); return -1; }
+  hipLaunchKernelGGL(sa_softmax_bwd_kernel, dim3(D1), dim3(256), 0, (hipStream_t)stream, dWd, dwd_pitch, W, mask, da, da_pitch,
+                     D1, C);
+  return check_launch("sa_softmax_backward");
 }
 
 extern "C" int sda_sa_weights_backward(const float* dWd, const float* W, const float* mask, const float* cosT,

@@ -226,7 +226,7 @@ class EncoderEngine:
         Xt = rows("Xt", d.Cp)
         ops.pack_rows(X, Xt)
         bufs["Xt"] = Xt
-        W_sa, Wp = ops.sa_weights_forward(P["z"], P["cos"], P["sin"], mask, d.D1p, d.Cp, dt)
+        W_sa, Wp = ops.sa_weights_forward(P["z"], P["cos"], P["sin"], mask, d.D1p, d.Cp, dt, fwd_table=P.get("sa_tab_f"))
         ctx.W_sa = W_sa
         h_sa = ops.conv_gemm(Xt, Wp, rows("h_sa", d.D1p), B=B, T=T, KS=1, dil=0, alg_dims=(d.C, d.D1))
         bufs["h_sa"] = h_sa
@@ -453,7 +453,8 @@ class EncoderEngine:
         tile_m = 160 if Cout_p % 160 == 0 else (128 if Cout_p % 128 == 0 else 64)
         perm, seg, nseg = self._uniform_segments(B, (Cout_p // tile_m) * (Cin_p // 64), dev)
         dWd = ops.reduce_slabs(ops.wgrad_gemm(dh_sa, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=perm, seg_start=seg, nseg=nseg))
-        grads["z"] = ops.sa_weights_backward(dWd, ctx.W_sa, ctx.mask, P["cosT"], P["sinT"], P["z"].shape[1])
+        grads["z"] = ops.sa_weights_backward(dWd, ctx.W_sa, ctx.mask, P["cosT"], P["sinT"], P["z"].shape[1],
+                                             bwd_table=P.get("sa_tab_b"))
         flush(["subj_w", "sb_w", "sb_b", "z"])
         join_side()
         for work in pending:

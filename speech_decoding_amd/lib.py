@@ -81,6 +81,8 @@ SIGNATURES = {
     "sda_reduce_slabs": (i32, [vp, vp, i32, i64, vp]),
     "sda_sa_weights_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "sda_sa_scratch_floats": (i32, [i32, i32, i32]),
+    "sda_sa_softmax_pack": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sda_sa_softmax_backward": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, vp]),
     "sda_sa_weights_backward": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_clip_logits_stats": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "sda_clip_grad": (i32, [vp, vp, vp, vp, vp, vp, f32, i32, vp, i64, vp, vp, vp, i32, i32, i32, vp]),

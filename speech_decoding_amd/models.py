@@ -61,10 +61,23 @@ class SpatialAttention(nn.Module):
         self.d_drop = float(args.d_drop)
         self._tables_T = None
 
+    def _tables_key(self):
+        # rebuilt when the buffers move or are written in place (load_state_dict copies into them)
+        return (str(self.cos.device), self.cos.data_ptr(), self.cos._version, self.sin._version)
+
     def transposed_tables(self):
-        if self._tables_T is None or self._tables_T[0].device != self.cos.device:
-            self._tables_T = (self.cos.t().contiguous(), self.sin.t().contiguous())
-        return self._tables_T
+        key = self._tables_key()
+        if self._tables_T is None or self._tables_T[0] != key:
+            self._tables_T = (key, self.cos.t().contiguous(), self.sin.t().contiguous())
+        return self._tables_T[1], self._tables_T[2]
+
+    def gemm_tables(self):
+        """Operand tables of the two contractions of the weight build for the matrix-core path (ops._sa_gemm_tables)."""
+        from . import ops
+        key = self._tables_key()
+        if getattr(self, "_tables_G", None) is None or self._tables_G[0] != key:
+            self._tables_G = (key,) + tuple(ops.sa_gemm_tables(self.cos, self.sin))
+        return self._tables_G[1], self._tables_G[2]
 
     def draw_mask(self) -> torch.Tensor:
         """models.py:81-83: one centre per forward from NumPy's global RNG; 0 within d_drop of it."""
@@ -212,6 +225,7 @@ class BrainEncoder(nn.Module):
         sa = self.subject_block.spatial_attention
         P["cos"], P["sin"] = sa.cos, sa.sin
         P["cosT"], P["sinT"] = sa.transposed_tables()
+        P["sa_tab_f"], P["sa_tab_b"] = sa.gemm_tables() if sa.cos.is_cuda else (None, None)
         for k in range(5):
             blk = getattr(self.conv_blocks, f"conv{k}")
             for j, bn in ((0, blk.batchnorm0), (1, blk.batchnorm1)):

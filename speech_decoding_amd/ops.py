@@ -406,20 +406,51 @@ def matmul_tn_typed(G, Ym, out, sub, rscale, *, M_rows, N_valid, K_cols, pitch, 
     return out
 
 
-def sa_weights_forward(z, cos_t, sin_t, mask, D1p, Cp, dtype):
+def sa_gemm_tables(cos_t: torch.Tensor, sin_t: torch.Tensor):
+    """Operand tables of SpatialAttention's two contractions, built from the (K2, C) cos/sin buffers:
+    forward  a[o][c] = sum_m Re z[o][m] cos[m][c] + Im z[o][m] sin[m][c]  ->  rows c of [cos | sin] interleaved in m,
+    backward dz[o][m] = sum_c da[o][c] (cos[m][c], sin[m][c])            ->  rows (2m, 2m+1), sensors padded to 64.
+    The owner of the buffers (models.SpatialAttention) caches them and rebuilds when the buffers change."""
+    K2, Cc = cos_t.shape
+    both = torch.stack([cos_t, sin_t], dim=-1)                                    # (K2, C, 2)
+    fwd = both.permute(1, 0, 2).reshape(Cc, 2 * K2).contiguous()
+    Cq = (Cc + 63) // 64 * 64
+    bwd = torch.zeros((2 * K2, Cq), dtype=torch.float32, device=cos_t.device)
+    bwd[:, :Cc] = both.permute(0, 2, 1).reshape(2 * K2, Cc)
+    return fwd, bwd
+
+
+def sa_weights_forward(z, cos_t, sin_t, mask, D1p, Cp, dtype, fwd_table=None):
+    """SpatialAttention weights (models.py:49-58) + dropout mask (81-84): W fp32 (D1, C) and the packed operand.
+    The (D1 x 2K2) . (2K2 x C) contraction runs on the fp32 matrix path (conv_gemm, split-K matrix mode)."""
     D1, K2 = z.shape
     Cc = cos_t.shape[1]
-    zr = torch.view_as_real(z).contiguous()
+    zr = torch.view_as_real(z).contiguous().view(D1, 2 * K2)
     W = torch.empty((D1, Cc), dtype=torch.float32, device=z.device)
     Wp = torch.empty((1, 1, D1p, Cp), dtype=dtype, device=z.device)
+    if fwd_table is not None and (2 * K2) % 64 == 0:   # the matrix path contracts in whole 64-element slabs
+        a = matmul_nt_splitk(zr, fwd_table, D1, Cc, 2 * K2, 2 * K2)                          # (D1, pad64(C)) fp32
+        L.check(L.load().sda_sa_softmax_pack(_p(a), a.shape[1], _p(mask), _p(W), _p(Wp), D1, Cc, D1p, Cp, dt_code(dtype), _st()),
+                "sa_softmax_pack")
+        return W, Wp
     scratch = torch.empty(L.load().sda_sa_scratch_floats(D1, K2, Cc), dtype=torch.float32, device=z.device)
     L.check(L.load().sda_sa_weights_forward(_p(zr), _p(cos_t), _p(sin_t), _p(mask), _p(W), _p(Wp), _p(scratch), D1, K2, Cc, D1p, Cp,
                                             dt_code(dtype), _st()), "sa_weights_forward")
     return W, Wp
 
 
-def sa_weights_backward(dWd, W, mask, cosT, sinT, K2):
+def sa_weights_backward(dWd, W, mask, cosT, sinT, K2, bwd_table=None):
+    """dWd fp32 (rows >= D1, pitch dWd.shape[-1]) -> dz complex64 (D1, K2).  With `bwd_table` (sa_gemm_tables) the
+    (D1 x C) . (C x 2K2) contraction runs on the fp32 matrix path; otherwise the stand-alone kernel is used."""
     D1, Cc = W.shape
+    if bwd_table is not None and (2 * K2) % 64 == 0:
+        bwd = bwd_table
+        Cq = bwd.shape[1]
+        da = torch.empty((D1, Cq), dtype=torch.float32, device=W.device)
+        L.check(L.load().sda_sa_softmax_backward(_p(dWd), dWd.shape[-1], _p(W), _p(mask), _p(da), Cq, D1, Cc, _st()),
+                "sa_softmax_backward")
+        dz = matmul_nt_splitk(da, bwd, D1, 2 * K2, Cq, Cq)                              # (D1, 2*K2) = (re, im) interleaved
+        return torch.view_as_complex(dz[:, : 2 * K2].reshape(D1, K2, 2))
     dz = torch.empty((D1, K2, 2), dtype=torch.float32, device=W.device)
     L.check(L.load().sda_sa_weights_backward(_p(dWd), _p(W), _p(mask), _p(cosT), _p(sinT), _p(dz), D1, K2, Cc, dWd.shape[-1],
                                              _st()), "sa_weights_backward")
