@@ -59,7 +59,7 @@ def cpu_baseline(batch: int):
                       f"{threads} torch threads, {dt:.1f} s"}
 
 
-def pmc_traffic(dtype: str, tile_co: int, ks: int):
+def pmc_traffic(dtype: str, tile_co: int, ks: int, kind: str = "conv_gemm"):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate rocprofv3 --pmc
     passes of this same command; tools/pmc_summary.py).  None when no summary matches."""
     import glob
@@ -68,7 +68,7 @@ def pmc_traffic(dtype: str, tile_co: int, ks: int):
         return None
     kernels = json.load(open(files[-1])).get("kernels", {})
     ctype = "unsigned short" if dtype == "bf16" else "float"
-    pre = f"void sda::conv_gemm_kernel<{ctype}, {tile_co}, {ks},"
+    pre = f"void sda::{kind}_kernel<{ctype}, {tile_co}, {ks},"
     hits = [v for k, v in kernels.items() if k.startswith(pre)]
     if not hits:
         return None
@@ -203,8 +203,8 @@ def main():
             ach = flops / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_TFLOPS[a.dtype], 4),
-                               "traffic": pmc_traffic(a.dtype, key[2], key[3]),
-                               "kernel": f"conv_gemm<{key[1]},TILE_CO={key[2]},KS={key[3]}>", "launches": n,
+                               "traffic": pmc_traffic(a.dtype, key[2], key[3], key[0]),
+                               "kernel": f"{key[0]}<{key[1]},TILE={key[2]},KS={key[3]}>", "launches": n,
                                "avg_us": round(1e3 * ms / n, 2)}
             out["kernel_time_ms_per_step"] = {f"{k[0]}<{k[1]},{k[2]},{k[3]}>": round(v[2] / timed_tail, 3) for k, v in summ.items()}
         if world == 1 and not a.no_cpu_baseline:

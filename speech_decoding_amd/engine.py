@@ -361,7 +361,8 @@ class EncoderEngine:
             perm, seg, nseg = self._uniform_segments(B, (Cout_p // tile_m) * (Cin_p // 64), dev)
 
             def chain():
-                slabs = ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=perm, seg_start=seg, nseg=nseg)
+                slabs = ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=perm, seg_start=seg, nseg=nseg,
+                                       alg_dims=(Cin, Cout))
                 return ops.reduce_unpack_wgrad(slabs, Cout, Cin, KS, **glu)
             return on_side(chain)
 

@@ -366,8 +366,9 @@ def colsum(x, B, T, scratch):
     return out
 
 
-def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1):
-    """fp32 slabs (nseg, KS, Cout_p, Cin_p) of dy^T x over the RL rows of the samples in each segment."""
+def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1, alg_dims=None):
+    """fp32 slabs (nseg, KS, Cout_p, Cin_p) of dy^T x over the RL rows of the samples in each segment.
+    alg_dims = (Cin, Cout) unpadded, only used to count algorithmic FLOPs when the timer is on."""
     a = L.WgradArgs()
     g = torch.empty((nseg, KS, dy.shape[1], x.shape[1]), dtype=torch.float32, device=x.device)
     a.dy, a.x, a.g, a.out_e, a.sub, a.rscale, a.out_scale = _p(dy), _p(x), _p(g), None, None, None, None
@@ -378,6 +379,16 @@ def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1):
     a.co_valid, a.dtype = 0, dt_code(x.dtype)
     if nseg > 1 and seg_start is None:
         raise L.SdaError("wgrad_gemm: nseg > 1 needs seg_start")
+    if TIMER is not None:              # events go on the CURRENT stream (the engine's side stream in backward)
+        cin, cout = alg_dims if alg_dims is not None else (x.shape[1], dy.shape[1])
+        tile_m = 160 if dy.shape[1] % 160 == 0 else (128 if dy.shape[1] % 128 == 0 else 64)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.load().sda_wgrad_gemm(C.byref(a), _st()), "wgrad_gemm")
+        e1.record()
+        TIMER.records.append((("wgrad_gemm", str(x.dtype).replace("torch.", ""), tile_m, KS),
+                              2.0 * B * T * KS * cin * cout, e0, e1))
+        return g
     L.check(L.load().sda_wgrad_gemm(C.byref(a), _st()), "wgrad_gemm")
     return g
 
