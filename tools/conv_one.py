@@ -10,7 +10,7 @@ def main():
     cin, cout, KS, dil = (int(v) for v in (sys.argv[2:6] if len(sys.argv) > 5 else (320, 320, 3, 4)))
     flags = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     n = int(os.environ.get("N", 20))
-    dev, B, T, dtype = "cuda:0", 256, 360, torch.bfloat16
+    dev, B, T, dtype = "cuda:0", 256, 360, (torch.float32 if os.environ.get("DTYPE") == "fp32" else torch.bfloat16)
     x = ops.new_rows(B, T, cin, dtype, dev); x.normal_()
     w = torch.randn(cout, cin, KS, device=dev) / math.sqrt(KS * cin)
     wp = ops.pack_conv_weight(w, cout, cin, dtype)
