@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="segments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--time-wgrad", action="store_true", help="also put HIP-event pairs around the weight-gradient GEMMs")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,7 +166,7 @@ def main():
     # `timed_tail` steps only: event pairs around every launch cost ~10 % of a step (they get in the way of
     # the two-stream overlap in backward), so instrumenting all K steps would distort `value`.
     timed_tail = 0 if a.no_kernel_timer else min(5, a.steps)
-    timer = ops.KernelTimer() if timed_tail else None
+    timer = ops.KernelTimer(("conv_gemm", "wgrad_gemm") if a.time_wgrad else ("conv_gemm",)) if timed_tail else None
     fence()
     t0 = time.perf_counter()
     for i in range(a.steps):

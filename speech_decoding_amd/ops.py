@@ -204,8 +204,9 @@ class KernelTimer:
     """Optional HIP-event timing of individual launches on the current stream (bench.py's roofline leg).
     Off by default: `ops.TIMER = KernelTimer()` turns it on, `ops.TIMER = None` off."""
 
-    def __init__(self):
+    def __init__(self, families=("conv_gemm",)):
         self.records = []           # (key, algorithmic_flops, start_event, end_event)
+        self.families = tuple(families)   # which kernel families get event pairs ("conv_gemm", "wgrad_gemm")
 
     def summary(self):
         torch.cuda.synchronize()
@@ -243,7 +244,7 @@ def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=N
         raise L.SdaError("conv_gemm: RL buffers too small for (B, T)")
     a.w_rows_limit, a.ksplit = y.shape[1], 1
     a.flags, a.dtype = (L.EPI_GELU if gelu else 0) | flags, dt_code(x.dtype)
-    if TIMER is not None:
+    if TIMER is not None and "conv_gemm" in TIMER.families:
         cin, cout = alg_dims if alg_dims is not None else (x.shape[1], y.shape[1])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -379,7 +380,7 @@ def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1, alg_d
     a.co_valid, a.dtype = 0, dt_code(x.dtype)
     if nseg > 1 and seg_start is None:
         raise L.SdaError("wgrad_gemm: nseg > 1 needs seg_start")
-    if TIMER is not None:              # events go on the CURRENT stream (the engine's side stream in backward)
+    if TIMER is not None and "wgrad_gemm" in TIMER.families:   # events go on the CURRENT stream (the side stream in backward)
         cin, cout = alg_dims if alg_dims is not None else (x.shape[1], dy.shape[1])
         tile_m = 160 if dy.shape[1] % 160 == 0 else (128 if dy.shape[1] % 128 == 0 else 64)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
