@@ -437,10 +437,11 @@ template <typename E, int TILE_CO>
 static int dispatch_conv_nt(const sda_conv_args& a, hipStream_t st) {
   const bool k3 = a.KS == 3;
   const int n_t = (a.T + TILE_T - 1) / TILE_T;
-  // two tiles per workgroup whenever tiles are independent of per-sample weights and there are enough of them
-  // Two tiles per workgroup (shared weight slab, 3-stage counted-vmcnt pipeline) measure the same as one
-  // tile x two workgroups per CU once the LDS-DMA is asm-issued (both are bound by DMA bytes in flight per
-  // CU), so the single-tile form is the default; SDA_CONV_PAIR_TILES selects the paired form.
+  // Two tiles per workgroup (shared weight slab, 3-stage counted-vmcnt pipeline) move 37 % fewer LDS-DMA bytes
+  // per FLOP and are the faster form when the kernel has the CU to itself (75 vs 83 us at 320->320), but they
+  // take the whole LDS of a CU (150 KB): the caller asks for them (SDA_CONV_PAIR_TILES) where nothing else wants
+  // the CU — the forward pass — and keeps the single-tile form (two 80 KB workgroups per CU, room for one
+  // weight-gradient workgroup beside them) in backward, where the paired form measured slower end to end.
   const bool pair = !a.widx && a.ksplit == 1 && (a.flags & SDA_CONV_PAIR_TILES) && !(a.flags & SDA_CONV_SINGLE_TILE);
   if (a.bn_x) {                 // BatchNorm-backward statistics epilogue: data-gradient convs of the k = 3 layers
     if (!k3) { set_error("conv_gemm: bn_x is built for kernel size 3 only"); return -1; }
