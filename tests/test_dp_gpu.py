@@ -86,11 +86,11 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process_global_batch():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_match_single_process_global_batch(world):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 29700 + (os.getpid() % 1000)
+    port = 29700 + (os.getpid() % 1000) + world
     procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
