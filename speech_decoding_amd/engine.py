@@ -317,7 +317,8 @@ class EncoderEngine:
             import torch.distributed as dist
             flats = [torch.view_as_real(grads[n]).reshape(-1) if grads[n].is_complex() else grads[n].reshape(-1) for n in names]
             bucket = torch.cat(flats)
-            work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            from .distributed import side_group
+            work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=side_group("grads", self.group), async_op=True)
             off = 0
             for n, f in zip(names, flats):
                 v = bucket[off: off + f.numel()]

@@ -102,8 +102,10 @@ def gather_speech_rows(Yt_local: torch.Tensor, B: int, T: int, group, async_op: 
     Tp = L.rows_tp(T)
     Yt = _ring_rows("loss.Yall", B * world, Yt_local.shape[1], T, Yt_local.dtype, Yt_local.device)
     ysq = torch.empty(B * world, dtype=torch.float32, device=Yt_local.device)
-    w1 = dist.all_gather_into_tensor(Yt[: B * world * Tp], Yt_local[: B * Tp], group=group, async_op=async_op)
-    w2 = dist.all_gather_into_tensor(ysq, ysq_local, group=group, async_op=async_op)
+    from .distributed import side_group
+    bulk = side_group("gather", group)          # own communicator: must not queue in front of the BatchNorm all-reduces
+    w1 = dist.all_gather_into_tensor(Yt[: B * world * Tp], Yt_local[: B * Tp], group=bulk, async_op=async_op)
+    w2 = dist.all_gather_into_tensor(ysq, ysq_local, group=bulk, async_op=async_op)
     return Yt, ysq, B * world, rank * B, B * world, ([w1, w2] if async_op else [])
 
 
