@@ -313,18 +313,23 @@ class EncoderEngine:
             re-point the gradients at views of the bucket (no copy back)."""
             if not overlap:
                 return
-            join_side()
             import torch.distributed as dist
-            flats = [torch.view_as_real(grads[n]).reshape(-1) if grads[n].is_complex() else grads[n].reshape(-1) for n in names]
-            bucket = torch.cat(flats)
             from .distributed import side_group
-            work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=side_group("grads", self.group), async_op=True)
+            flats = [torch.view_as_real(grads[n]).reshape(-1) if grads[n].is_complex() else grads[n].reshape(-1) for n in names]
+
+            def pack_and_reduce():
+                # on the SIDE stream, where the weight gradients of this group are produced: the main stream (the
+                # critical path) never waits for them; on_side() makes the side stream wait for the few gradients
+                # that come from the main stream (biases, BatchNorm affine)
+                b = torch.cat(flats)
+                pending.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=side_group("grads", self.group), async_op=True))
+                return b
+            bucket = on_side(pack_and_reduce)
             off = 0
             for n, f in zip(names, flats):
                 v = bucket[off: off + f.numel()]
                 grads[n] = torch.view_as_complex(v.view(*grads[n].shape, 2)) if grads[n].is_complex() else v.view(grads[n].shape)
                 off += f.numel()
-            pending.append(work)
 
         def tmp(name, Cp):
             return self._rows("bw." + name, B, T, Cp, dev, "train")
