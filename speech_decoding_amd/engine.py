@@ -322,6 +322,9 @@ class EncoderEngine:
                 # critical path) never waits for them; on_side() makes the side stream wait for the few gradients
                 # that come from the main stream (biases, BatchNorm affine)
                 b = torch.cat(flats)
+                if side is not None:
+                    for f in flats:               # sources made on the main stream are read here, on the side stream
+                        f.record_stream(side)
                 pending.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=side_group("grads", self.group), async_op=True))
                 return b
             bucket = on_side(pack_and_reduce)
