@@ -152,6 +152,12 @@ int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const float* mean
 /* out0[c] = sum_k partial[k][0][c] (and out1 from [k][1][c] when out1 != NULL): fixed-order fp64 reduction of
  * per-tile statistics written by sda_conv_gemm (`stats`), e.g. the BatchNorm backward sums of bn_x mode. */
 int sda_reduce_stats(const float* partial, int nrows, float* out0, float* out1, int Cp, void* stream);
+/* Single-process shortcut: per-tile sums (sda_conv_gemm bn_x mode) -> dgamma/dbeta + coefficient table in ONE
+ * launch, then the apply pass.  (Data-parallel runs use sda_reduce_stats, all-reduce the two sums, then ..._apply.) */
+int sda_bn_gelu_backward_from_stats(const float* partial, int nrows, const void* dy, const void* x, const float* mean,
+                                    const float* rstd, const float* gamma, const float* beta, int C, double count,
+                                    float* dgamma, float* dbeta, float* coef, void* dx, int B, int T, int Cp, int dtype,
+                                    void* stream);
 int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean, const float* rstd,
                                const float* gamma, const float* beta, int C, const float* dgamma,
                                const float* dbeta, double count, float* coef /* 6*Cp floats scratch */, void* dx,

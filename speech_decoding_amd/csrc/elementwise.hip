@@ -458,6 +458,27 @@ __global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* 
   coef[5 * Cp + c] = dgamma[c] * inv_count;
 }
 
+// reduce_stats + bn_bwd_coef in one launch (single-process case: no all-reduce sits between them)
+__global__ __launch_bounds__(256) void bn_bwd_stats_coef_kernel(const float* __restrict__ partial, int nrows,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int C, float inv_count, float* __restrict__ dbeta,
+                                                                float* __restrict__ dgamma, float* __restrict__ coef, int Cp) {
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  double s0, s1;
+  block_partial_sums(partial, nrows, Cp, blockIdx.x * 8, true, s0, s1);
+  if (threadIdx.x >= 8 || c >= Cp) return;
+  const float db = (float)s0, dg = (float)s1;
+  dbeta[c] = db;
+  dgamma[c] = dg;
+  coef[0 * Cp + c] = c < C ? gamma[c] : 0.f;
+  coef[1 * Cp + c] = c < C ? beta[c] : 0.f;
+  coef[2 * Cp + c] = mean[c];
+  coef[3 * Cp + c] = rstd[c];
+  coef[4 * Cp + c] = db * inv_count;
+  coef[5 * Cp + c] = dg * inv_count;
+}
+
 template <typename E>
 __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restrict__ dy, const E* __restrict__ x,
                                                                 const float* __restrict__ coef, E* __restrict__ dx,
@@ -777,6 +798,23 @@ extern "C" int sda_bn_gelu_backward_apply(const void* dy, const void* x, const f
   SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, st,
                                          (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
   return check_launch("bn_gelu_backward_apply");
+}
+
+extern "C" int sda_bn_gelu_backward_from_stats(const float* partial, int nrows, const void* dy, const void* x,
+                                              const float* mean, const float* rstd, const float* gamma,
+                                              const float* beta, int C, double count, float* dgamma, float* dbeta,
+                                              float* coef, void* dx, int B, int T, int Cp, int dtype, void* stream) {
+  if (!partial || nrows < 1 || !dy || !x || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !coef || !dx ||
+      Cp % 64 || count < 1.0) {
+    set_error("bn_gelu_backward_from_stats: bad arguments"); return -1;
+  }
+  const size_t total = (size_t)B * T * (Cp / 4);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_stats_coef_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, partial, nrows, mean, rstd, gamma, beta, C,
+                     (float)(1.0 / count), dbeta, dgamma, coef, Cp);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, st,
+                                         (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
+  return check_launch("bn_gelu_backward_from_stats");
 }
 
 extern "C" int sda_colsum(const void* x, float* out, float* scratch, int B, int T, int Cp, int dtype, void* stream) {

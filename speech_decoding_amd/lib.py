@@ -67,6 +67,7 @@ SIGNATURES = {
     "sda_conv_n_t_tiles": (i32, [i32]),
     "sda_bn_finalize": (i32, [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "sda_reduce_stats": (i32, [vp, i32, vp, vp, i32, vp]),
+    "sda_bn_gelu_backward_from_stats": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, f64, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_bn_gelu_forward": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_bn_gelu_backward_reduce": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_bn_gelu_backward_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, f64, vp, vp, i32, i32, i32, i32, vp]),

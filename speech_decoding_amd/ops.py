@@ -317,6 +317,13 @@ def bn_gelu_backward(dy, x, mean, rstd, gamma, beta, dx, B, T, scratch, count=No
     sums = torch.empty((2, Cp), dtype=torch.float32, device=x.device)
     dgamma, dbeta = sums[0], sums[1]
     lib = L.load()
+    if tile_stats is not None and allreduce is None:          # single process: sums + coefficients in one launch
+        coef = torch.empty(6 * Cp, dtype=torch.float32, device=x.device)
+        L.check(lib.sda_bn_gelu_backward_from_stats(_p(tile_stats), tile_stats.shape[0], _p(dy), _p(x), _p(mean), _p(rstd),
+                                                    _p(gamma), _p(beta), gamma.numel(), float(count if count is not None else B * T),
+                                                    _p(dgamma), _p(dbeta), _p(coef), _p(dx), B, T, Cp, dt_code(x.dtype), _st()),
+                "bn_gelu_backward_from_stats")
+        return dgamma, dbeta
     if tile_stats is not None:
         L.check(lib.sda_reduce_stats(_p(tile_stats), tile_stats.shape[0], _p(dbeta), _p(dgamma), Cp, _st()), "reduce_stats")
     else:
