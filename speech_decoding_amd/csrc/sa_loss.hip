@@ -223,9 +223,17 @@ __global__ __launch_bounds__(256) void clip_grad_kernel(const float* __restrict_
 }
 
 __global__ void clip_scalars_kernel(const float* __restrict__ colpart, float inv_norm, float* __restrict__ scalars, int Bn) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: lane-strided fp64 partial sums, then lane 0 adds the 64 partials in lane order (deterministic)
+  __shared__ double pl[64], pd[64];
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
   double l = 0.0, dt = 0.0;
-  for (int j = 0; j < Bn; ++j) { l += (double)colpart[j * 2]; dt += (double)colpart[j * 2 + 1]; }
+  for (int j = threadIdx.x; j < Bn; j += 64) { l += (double)colpart[j * 2]; dt += (double)colpart[j * 2 + 1]; }
+  pl[threadIdx.x] = l;
+  pd[threadIdx.x] = dt;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  l = 0.0; dt = 0.0;
+  for (int k = 0; k < 64; ++k) { l += pl[k]; dt += pd[k]; }
   scalars[0] = (float)(l * (double)inv_norm);
   scalars[1] = (float)dt;
 }
