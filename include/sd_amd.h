@@ -57,6 +57,9 @@ int sda_unpack_rows(const void* src, float* dst, int B, int C, int T, int Cp, in
  * pitch `pitch` (elements). out[b] fp32. `scratch` holds B*64 floats. */
 int sda_rows_sumsq(const void* x, float* out, float* scratch, int B, long row_elems, long pitch,
                    int dtype, void* stream);
+/* the same norms for a tensor a conv just produced, from that conv's per-tile statistics ([B * tiles_per_sample][2][Cp],
+ * plane 1 = sum of squares of the stored values): no second pass over the tensor */
+int sda_rows_sumsq_from_stats(const float* stats, int tiles_per_sample, int Cp, float* out, int B, void* stream);
 
 /* fp32 conv weight [nW][Cout][Cin][KS]  ->  packed `dtype` operand.
  * mode 0 (forward):  dst[n][tap][co'][ci]  = w[n][co][ci][tap]

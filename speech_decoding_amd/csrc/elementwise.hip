@@ -78,6 +78,26 @@ __global__ void rows_sumsq_final_kernel(const float* __restrict__ scratch, float
   out[b] = (float)s;
 }
 
+// per-sample sum of squares from the per-tile channel statistics a conv epilogue already wrote
+// (stats[tile][1][c] = sum over the tile's valid rows of y^2): out[b] = sum over the sample's tiles and all channels
+__global__ __launch_bounds__(256) void rows_sumsq_from_stats_kernel(const float* __restrict__ stats, int tiles_per_sample,
+                                                                    int Cp, float* __restrict__ out) {
+  __shared__ double sh[256];
+  const int b = blockIdx.x;
+  double s = 0.0;
+  for (int t = 0; t < tiles_per_sample; ++t) {
+    const float* p = stats + (((size_t)b * tiles_per_sample + t) * 2 + 1) * Cp;
+    for (int c = threadIdx.x; c < Cp; c += 256) s += (double)p[c];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {                      // fixed tree: deterministic
+    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[b] = (float)sh[0];
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight / vector packing
 // ------------------------------------------------------------------------------------------------
@@ -627,6 +647,12 @@ extern "C" int sda_unpack_rows(const void* src, float* dst, int B, int C, int T,
   dim3 grid((T + 63) / 64, Cp / 64, B);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL(unpack_rows_kernel<E>, grid, dim3(256), 0, st, (const E*)src, dst, C, T, Cp));
   return check_launch("unpack_rows");
+}
+
+extern "C" int sda_rows_sumsq_from_stats(const float* stats, int tiles_per_sample, int Cp, float* out, int B, void* stream) {
+  if (!stats || !out || tiles_per_sample < 1 || Cp < 1 || B < 1) { set_error("rows_sumsq_from_stats: bad arguments"); return -1; }
+  hipLaunchKernelGGL(rows_sumsq_from_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, stats, tiles_per_sample, Cp, out);
+  return check_launch("rows_sumsq_from_stats");
 }
 
 extern "C" int sda_rows_sumsq(const void* x, float* out, float* scratch, int B, long row_elems, long pitch,

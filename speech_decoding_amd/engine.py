@@ -284,8 +284,11 @@ class EncoderEngine:
         ops.conv_gemm(x, pk["f1w"], g1, B=B, T=T, KS=1, dil=0, bias=pk["f1b"], y_pre=u1 if need_grad else None,
                       gelu=True, alg_dims=(d.D2, d.F1))
         u2, Zt = rows("u2", d.Fp), self._rows("Z", B, T, d.Fp, dev, space)
+        zstats = torch.empty((B * ops.n_t_tiles(T), 2, d.Fp), dtype=torch.float32, device=dev)
         ops.conv_gemm(g1, pk["f2w"], Zt, B=B, T=T, KS=1, dil=0, bias=pk["f2b"], y_pre=u2 if need_grad else None,
-                      gelu=True, alg_dims=(d.F1, d.F))
+                      gelu=True, stats=zstats, alg_dims=(d.F1, d.F))
+        # ||Z_b||^2 for the loss comes out of the epilogue's per-tile sums: no separate pass over Z (loss.py:65)
+        ops.ROW_NORMS.put(Zt, ops.rows_sumsq_from_stats(zstats, B))
         bufs.update(u1=u1, g1=g1, u2=u2, Z=Zt)
         if not need_grad:
             ctx.bufs = {"Z": Zt}
@@ -519,7 +522,9 @@ def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: 
     row_elems = L.rows_tp(T) * Fp
     if ysq is None:                              # (under DP the caller gathers the per-rank norms instead)
         ysq = ops.rows_sumsq(Yt, Bm, row_elems, row_elems)
-    zsq = ops.rows_sumsq(Zt, Bn, row_elems, row_elems)
+    zsq = ops.ROW_NORMS.get(Zt, Bn)              # left by the encoder's last conv when Zt is its output buffer
+    if zsq is None:
+        zsq = ops.rows_sumsq(Zt, Bn, row_elems, row_elems)
     S = ops.matmul_nt_splitk(Yt, Zt, Bm, Bn, row_elems, row_elems)
     logits, row_max, row_sum, col_lse, diag = ops.clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0)
     from .distributed import merge_row_softmax_stats

@@ -56,6 +56,7 @@ SIGNATURES = {
     "sda_pack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sda_unpack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sda_rows_sumsq": (i32, [vp, vp, vp, i32, i64, i64, i32, vp]),
+    "sda_rows_sumsq_from_stats": (i32, [vp, i32, i32, vp, i32, vp]),
     "sda_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "sda_adam_multi": (i32, [vp, i32, i64, f32, f32, f32, f32, i64, vp]),
     "sda_pack_multi": (i32, [vp, i32, i64, i32, vp]),

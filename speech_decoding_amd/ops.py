@@ -108,6 +108,37 @@ def rows_sumsq(x: torch.Tensor, B: int, row_elems: int, pitch: int) -> torch.Ten
     return out
 
 
+def rows_sumsq_from_stats(stats: torch.Tensor, B: int) -> torch.Tensor:
+    """Per-sample sum of squares of a conv output from the per-tile statistics its epilogue wrote (plane 1)."""
+    out = torch.empty(B, dtype=torch.float32, device=stats.device)
+    L.check(L.load().sda_rows_sumsq_from_stats(_p(stats), stats.shape[0] // B, stats.shape[2], _p(out), B, _st()),
+            "rows_sumsq_from_stats")
+    return out
+
+
+class _NormCache:
+    """Squared norms of RL buffers whose producer already summed them (the encoder's last conv).  An entry is valid only
+    for the same storage at the same torch version counter: an in-place torch op on the tensor (or any view of it)
+    invalidates it; the producing kernel refreshes it on every forward."""
+
+    def __init__(self):
+        self.items = {}
+
+    def put(self, buf: torch.Tensor, sumsq: torch.Tensor):
+        if len(self.items) > 16:
+            self.items.clear()
+        self.items[buf.data_ptr()] = (buf._version, buf.shape[0], sumsq)
+
+    def get(self, buf: torch.Tensor, B: int):
+        hit = self.items.get(buf.data_ptr())
+        if hit is None or hit[0] != buf._version or hit[1] != buf.shape[0] or hit[2].numel() != B:
+            return None
+        return hit[2]
+
+
+ROW_NORMS = _NormCache()
+
+
 def pack_conv_weight(w: torch.Tensor, Cout_p: int, Cin_p: int, dtype, mode: int = 0, glu_half: int = 0,
                      glu_half_p: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """w: (nW, Cout, Cin, KS) or (Cout, Cin, KS) fp32 -> packed operand (nW, KS, rows, cols)."""
