@@ -392,15 +392,22 @@ class EncoderEngine:
                           bn_x=bn[0], bn_coef=bn[1], alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]))
             return out, st
 
+        def bias_grad(cs, C, glu_half=0, glu_half_p=0):
+            """Padded column sums -> bias gradient: a view when the unpadded vector is a prefix of the padded one (no GLU
+            split, or GLU halves without padding between them); the un-packing kernel otherwise."""
+            if glu_half == 0 or glu_half_p == glu_half:
+                return cs[:C]
+            return ops.unpack_vector(cs, C, glu_half, glu_half_p)
+
         # ---- final projections
         du2 = tmp("du2", d.Fp)
         cs = ops.gelu_backward_colsum(bufs["u2"], dZt, du2, B, T, scratch)
-        grads["f2b"] = ops.unpack_vector(cs, d.F)
+        grads["f2b"] = bias_grad(cs, d.F)
         dg1, _ = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
         grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
         du1 = tmp("du1", d.F1p)
         cs = ops.gelu_backward_colsum(bufs["u1"], dg1, du1, B, T, scratch)
-        grads["f1b"] = ops.unpack_vector(cs, d.F1)
+        grads["f1b"] = bias_grad(cs, d.F1)
         dx, _ = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
         grads["f1w"] = wgrad(du1, bufs["x5"], 1, 0, d.F1, d.D2)
         flush(["f2w", "f2b", "f1w", "f1b"])
@@ -414,7 +421,7 @@ class EncoderEngine:
             glu = dict(glu_half=d.D2, glu_half_p=d.D2p)
             dc2 = tmp(f"dc2.{k}", 2 * d.D2p)          # per-layer buffers: a side-stream wgrad may still read them
             cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
-            grads[f"b{k}.c2b"] = ops.unpack_vector(cs, 2 * d.D2, **glu)
+            grads[f"b{k}.c2b"] = bias_grad(cs, 2 * d.D2, **glu)
             da1, tstats = dgrad(dc2, f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2],
                                 bn=(bufs[f"b{k}.h1"], ctx.bn[f"b{k}.bn1"][2]), **glu)
             # the weight-gradient chain is queued AFTER the data-gradient conv: on the side stream it then runs
@@ -460,7 +467,7 @@ class EncoderEngine:
         grads["subj_w"] = on_side(subj_wgrad)
         dh_c, _ = dgrad(dhs, "subj_w", P["subj_w"], d.D1p, d.D1p, tmp("dh_c", d.D1p), 1, 0, widx=ctx.widx)
         grads["sb_w"] = wgrad(dh_c, bufs["h_sa"], 1, 0, d.D1, d.D1)
-        grads["sb_b"] = ops.unpack_vector(ops.colsum(dh_c, B, T, scratch), d.D1)
+        grads["sb_b"] = bias_grad(ops.colsum(dh_c, B, T, scratch), d.D1)
         dh_sa, _ = dgrad(dh_c, "sb_w", P["sb_w"], d.D1p, d.D1p, tmp("dh_sa", d.D1p), 1, 0)
         Cout_p, Cin_p = d.D1p, d.Cp
         tile_m = 160 if Cout_p % 160 == 0 else (128 if Cout_p % 128 == 0 else 64)
