@@ -118,22 +118,28 @@ def rows_sumsq_from_stats(stats: torch.Tensor, B: int) -> torch.Tensor:
 
 class _NormCache:
     """Squared norms of RL buffers whose producer already summed them (the encoder's last conv).  An entry is valid only
-    for the same storage at the same torch version counter: an in-place torch op on the tensor (or any view of it)
+    while the PRODUCER'S tensor object is alive (a freed buffer's address can be handed to an unrelated tensor), for
+    the same storage at the same torch version counter: an in-place torch op on the tensor (or any view of it)
     invalidates it; the producing kernel refreshes it on every forward."""
 
     def __init__(self):
         self.items = {}
 
     def put(self, buf: torch.Tensor, sumsq: torch.Tensor):
+        import weakref
         if len(self.items) > 16:
-            self.items.clear()
-        self.items[buf.data_ptr()] = (buf._version, buf.shape[0], sumsq)
+            self.items = {k: v for k, v in self.items.items() if v[0]() is not None}
+        self.items[buf.data_ptr()] = (weakref.ref(buf), buf._version, buf.shape[0], sumsq)
 
     def get(self, buf: torch.Tensor, B: int):
         hit = self.items.get(buf.data_ptr())
-        if hit is None or hit[0] != buf._version or hit[1] != buf.shape[0] or hit[2].numel() != B:
+        if hit is None:
             return None
-        return hit[2]
+        owner = hit[0]()
+        if (owner is None or owner.data_ptr() != buf.data_ptr() or owner._version != hit[1] or buf._version != hit[1]
+                or hit[2] != buf.shape[0] or hit[3].numel() != B):
+            return None
+        return hit[3]
 
 
 ROW_NORMS = _NormCache()

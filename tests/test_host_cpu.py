@@ -129,3 +129,27 @@ def test_subject_segments_partition_the_batch_slice_major(S, r, B):
         assert sum(sizes) == int((sidx == s).sum()) and max(sizes) - min(sizes) <= 1
         joined = np.concatenate(members) if members else np.empty(0, dtype=np.int32)
         assert (np.diff(joined) > 0).all()                   # stable: ascending sample index within a subject
+
+
+def test_norm_cache_entries_die_with_their_producer_and_on_inplace_edits():
+    """ops.ROW_NORMS: norms left by the encoder are served only to the same live buffer at the same version; a freed
+    buffer whose address is reused by another tensor must not inherit them (an intermittent wrong-loss bug once)."""
+    from speech_decoding_amd.ops import _NormCache
+    cache = _NormCache()
+    buf = torch.zeros(40, 8)
+    norms = torch.arange(4.0)
+    cache.put(buf, norms)
+    view = buf.detach().as_strided((40, 8), (8, 1), 0)              # what loss.as_rows hands to clip_forward
+    assert cache.get(view, 4) is norms
+    assert cache.get(view, 5) is None                               # different batch size
+    buf[3].add_(1.0)                                                # in-place edit through any view bumps the version
+    assert cache.get(view, 4) is None
+    cache.put(buf, norms)
+    assert cache.get(view, 4) is norms
+    ptr = buf.data_ptr()
+    del buf, view
+    for _ in range(64):                                             # try to get the freed address back
+        other = torch.zeros(40, 8)
+        if other.data_ptr() == ptr:
+            assert cache.get(other, 4) is None
+            break
