@@ -1,99 +1,186 @@
 #!/usr/bin/env python3
 """bench.py — training throughput of the contrastive hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--batch B_per_gpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp16|fp32] [--batch B_per_gpu]
 
 One step = BrainEncoder forward + CLIPLoss + top-k ranks + backward + (N > 1: gradient all-reduce) + Adam
 on one synthetic Gwilliams2022-shaped batch (208 sensors x 360 samples, 27 subjects, F = 1024,
 256 segments per GPU; BASELINE.json configs[1] at N = 1, configs[2] at N = 8) that is already resident
 in HBM.  Weak scaling: the per-GPU batch is fixed, negatives span the global batch.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
-(conv_gemm k=3, measured with HIP events on the launch stream) and, at N = 1, `cpu_baseline` (the CPU
-oracle timed on this box's host cores on one config-② step).
+
+`python bench.py --gpus N` with N > 1 starts its own ranks: a CHILD `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` is spawned before this process touches the GPU, and its exit code is returned.
+Under `torch.distributed.run` (RANK/WORLD_SIZE set) it runs as one rank.
+
+Timing: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize fences with NO instrumentation
+inside; `value` = global segments / max-over-ranks time.  The roofline leg (HIP-event pairs around every launch of the
+GEMM-class kernels, on the stream they are launched on) runs AFTER the timed region on a few extra steps, so it cannot
+change `value`.  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel) and, at N = 1, `cpu_baseline`
+(the CPU oracle timed on this box's host cores, BASELINE.md §3 procedure on a bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import warnings
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 C, S, T, F, D1, D2, K = 208, 27, 360, 1024, 270, 320, 32
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 
 
-def cpu_baseline(batch: int):
-    """Oracle (CPU restatement of the reference, pinned on the golden fixtures) timed on the host cores:
-    ONE config-② training step (forward + loss + backward + Adam) after a small warm-up."""
-    from oracle import brain_oracle as O
-    threads = torch.get_num_threads()
-    loc = O.synthetic_positions(C, seed=0)
-    P = O.seeded_params(C, S, D1, D2, F, K, seed=0, loc=loc)
-    temp = torch.tensor([5.1])
-
-    def one(B, seed):
-        X, Y, subj = O.synthetic_batch(B, C, T, F, S, seed=seed)
-        t0 = time.perf_counter()
-        loss, Z, logits, grads = O.train_step(P, temp, X, Y, subj, loc=loc, drop_centre=3)
-        params = [P[k] for k in grads if k != "temp" and grads[k] is not None]
-        for p, k in zip(params, [k for k in grads if k != "temp" and grads[k] is not None]):
-            p.grad = grads[k]
-        opt = torch.optim.Adam([p.requires_grad_(True) for p in params], lr=3e-4)
-        opt.step()
-        O.topk_accuracy(Z, Y)
-        for p in params:
-            p.requires_grad_(False)
-            p.grad = None
-        return time.perf_counter() - t0
-
-    one(16, 1)
-    dt = one(batch, 2)
-    return {"value": round(batch / dt, 3), "unit": "segments/s", "cores": threads, "kind": "port",
-            "sample": f"1 training step (fwd+loss+top-k+bwd+Adam) at batch {batch}, 208ch x 360, fp32, "
-                      f"{threads} torch threads, {dt:.1f} s"}
-
-
-def pmc_traffic(dtype: str, tile_co: int, ks: int, kind: str = "conv_gemm"):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate rocprofv3 --pmc
-    passes of this same command; tools/pmc_summary.py).  None when no summary matches."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    if not files:
-        return None
-    kernels = json.load(open(files[-1])).get("kernels", {})
-    ctype = "unsigned short" if dtype == "bf16" else "float"
-    pre = f"void sda::{kind}_kernel<{ctype}, {tile_co}, {ks},"
-    hits = [v for k, v in kernels.items() if k.startswith(pre)]
-    if not hits:
-        return None
-    n = sum(h["launches"] for h in hits)
-    return round(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / n)
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--batch", type=int, default=256, help="segments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--time-wgrad", action="store_true", help="also put HIP-event pairs around the weight-gradient GEMMs")
-    a = ap.parse_args()
+    ap.add_argument("--timer-steps", type=int, default=3, help="instrumented steps run after the timed region")
+    ap.add_argument("--no-host-sync-leg", action="store_true", help="skip the extra loop that reads loss/ranks back every step")
+    return ap.parse_args()
 
+
+def spawn_ranks(a):
+    """--gpus N from a bare `python bench.py`: start N ranks as a child process (nothing here has touched the GPU:
+    torch is not even imported yet) and hand back its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def host_cores():
+    """Cores this process may use: CPU affinity, cgroup CPU quota and physical (non-SMT) cores, whichever is smallest."""
+    aff = sorted(os.sched_getaffinity(0))
+    n = len(aff)
+    phys = set()
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in aff:
+                    phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if phys:
+            n = min(n, len(phys))
+    except OSError:
+        pass
+    model = "?"
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n), model
+
+
+def cpu_baseline(batch: int, budget_s: float = 40.0):
+    """Oracle (CPU restatement of the reference, pinned on the golden fixtures) timed on the host cores, following
+    BASELINE.md §3: torch threads = physical cores available to this process, 2 warm-up steps, then timed training
+    steps (forward + loss + top-k as a matmul + backward + Adam) at config ② (208 ch, batch 256, 27 subjects) and
+    config ① (60 ch, batch 64, 1 subject); bounded: each config stops after 3 steps or `budget_s` seconds."""
+    import torch
+    from oracle import brain_oracle as O
+    cores, model = host_cores()
+    torch.set_num_threads(cores)
+    temp = torch.tensor([5.1])
+
+    def run(Cc, Ss, B, max_steps, budget):
+        loc = O.synthetic_positions(Cc, seed=0)
+        P = O.seeded_params(Cc, Ss, D1, D2, F, K, seed=0, loc=loc)
+        names = None
+        opt = None
+        times = []
+
+        def one(Bx, seed):
+            nonlocal names, opt
+            X, Y, subj = O.synthetic_batch(Bx, Cc, T, F, Ss, seed=seed)
+            t0 = time.perf_counter()
+            loss, Z, logits, grads = O.train_step(P, temp, X, Y, subj, loc=loc, drop_centre=3)
+            if names is None:
+                names = [k for k in grads if k != "temp" and grads[k] is not None]
+                opt = torch.optim.Adam([P[k].requires_grad_(True) for k in names], lr=3e-4)
+            for k in names:
+                P[k].grad = grads[k]
+            opt.step()
+            O.topk_accuracy(Z, Y)
+            for k in names:
+                P[k].grad = None
+            return time.perf_counter() - t0
+
+        one(12, 1)
+        one(12, 2)                                    # 2 warm-up steps (thread pool, allocator, mkldnn primitives)
+        t_start = time.perf_counter()
+        while len(times) < max_steps and (not times or time.perf_counter() - t_start + times[-1] < budget):
+            times.append(one(B, 10 + len(times)))
+        return B * len(times) / sum(times), times
+
+    v2, t2 = run(C, S, batch, 3, budget_s)
+    v1, t1 = run(60, 1, 64, 3, budget_s / 2)
+    par = [l.strip() for l in torch.__config__.parallel_info().splitlines() if "get_num_threads" in l or "OpenMP" in l or "MKL" in l.upper()]
+    return {"value": round(v2, 3), "unit": "segments/s", "cores": cores, "kind": "port",
+            "sample": f"config 2 (208ch x 360, batch {batch}, 27 subj): {len(t2)} timed training steps of "
+                      f"{', '.join(f'{x:.1f}' for x in t2)} s after 2 warm-up steps; config 1 (60ch, batch 64, 1 subj): "
+                      f"{len(t1)} steps -> {v1:.2f} segments/s; fp32, step = fwd+loss+top-k(matmul)+bwd+Adam",
+            "config1_value": round(v1, 3), "cpu_model": model, "torch_threads": cores,
+            "parallel_info": "; ".join(par)[:300]}
+
+
+def pmc_traffic(dtype: str, tile_co: int, ks: int, kind: str = "conv_gemm"):
+    """HBM bytes per launch of the dominant kernel, launch-weighted over its instantiations, from the newest committed
+    PMC summary (separate `rocprofv3 --pmc` passes of this same command; tools/pmc_summary.py).  Returns
+    (bytes or None, source file or None): the counters cannot be collected from inside this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    kernels = json.load(open(files[-1])).get("kernels", {})
+    ctype = {"bf16": "unsigned short", "fp16": "_Float16", "fp32": "float"}[dtype]
+    hits = [v for k, v in kernels.items() if f"{kind}" in k and f"<{ctype}, {tile_co}, {ks}," in k]
+    if not hits:
+        return None, os.path.relpath(files[-1], ROOT)
+    n = sum(h["launches"] for h in hits)
+    return round(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / n), os.path.relpath(files[-1], ROOT)
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a))
+
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
     # rehearsal-only overrides (several ranks on a one-GPU box): SDA_FORCE_DEVICE=0 SDA_DIST_BACKEND=gloo
     local = int(os.environ.get("SDA_FORCE_DEVICE", local))
@@ -107,7 +194,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from speech_decoding_amd import Classifier, BrainEncoder, CLIPLoss, load_config, ops
+    from speech_decoding_amd import BrainEncoder, CLIPLoss, load_config, ops
     from speech_decoding_amd.layout import synthetic_positions
     from speech_decoding_amd import loss as sda_loss
     from speech_decoding_amd.distributed import allreduce_gradients, broadcast_parameters
@@ -126,28 +213,37 @@ def main():
     params = list(enc.parameters()) + list(lossf.parameters())
     from speech_decoding_amd.optim import FusedAdam        # same rule as torch.optim.Adam, one launch
     opt = FusedAdam(params, lr=float(cfg.lr))
+    from speech_decoding_amd.amp import LossScaler
+    scaler = LossScaler.for_dtype(enc.compute_dtype)        # static loss scale for fp16; a no-op for bf16 / fp32
 
-    # synthetic data pool resident in HBM: X ~ N(0,1) clamped ±20; Y = P·X + 0.5·eps (learnable structure)
+    # synthetic data pool resident in HBM: X ~ N(0,1) clamped ±20; Y = P·X + 0.5·eps (learnable structure).
+    # Subject indices are drawn FRESH every step (as a data loader delivers them), so the per-step index uploads are real.
     B = a.batch
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     Pm = torch.randn(F, C, generator=torch.Generator().manual_seed(7)).to(dev) / np.sqrt(C)
     pool = []
-    for i in range(3):
+    for i in range(4):
         X = torch.randn(B, C, T, generator=g, device=dev).clamp_(-20, 20)
         Y = torch.einsum("fc,bct->bft", Pm, X) + 0.5 * torch.randn(B, F, T, generator=g, device=dev)
-        subj = torch.randint(0, S, (B,), generator=torch.Generator().manual_seed(100 * rank + i), dtype=torch.int32)
-        pool.append((X, Y.contiguous(), subj))
+        pool.append((X, Y.contiguous()))
+    subj_rng = np.random.RandomState(100 + rank)
 
     ranks_acc = []
 
-    def step(i):
-        X, Y, subj = pool[i % len(pool)]
+    def step(i, host_sync=False):
+        X, Y = pool[i % len(pool)]
+        subj = torch.from_numpy(subj_rng.randint(0, S, size=B).astype(np.int32))
         lossf.prefetch(Y, enc.compute_dtype)                 # pack Y (+ all-gather it under DP) while the encoder runs
         Z = enc(X, subj)
         loss = lossf(Y, Z)
-        ranks_acc.append(sda_loss.retrieval_ranks(Y, Z))     # Classifier semantics (train.py:193-194), kept on device
+        cnt = sda_loss.retrieval_ranks(Y, Z)                 # Classifier semantics (train.py:193-194)
+        if host_sync:                                        # what train.py does every step: loss.item() + top-k on the host
+            float(loss.detach())
+            cnt = cnt.cpu()
+        ranks_acc.append(cnt)
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        scaler.scale(loss).backward()
+        scaler.unscale_(params)
         if world > 1:      # encoder gradients were all-reduced inside backward (overlapped); temp is left
             allreduce_gradients(list(lossf.parameters()) if enc.grads_are_reduced else params)
         opt.step()
@@ -159,31 +255,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, first, **kw):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n):
+            loss = step(first + i, **kw)
+        fence()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), loss
+
     for i in range(a.warmup):
         step(i)
     ranks_acc.clear()
-    # HIP-event timing of the dominant kernel's launches runs inside the timed region, on its last
-    # `timed_tail` steps only: event pairs around every launch cost ~10 % of a step (they get in the way of
-    # the two-stream overlap in backward), so instrumenting all K steps would distort `value`.
-    timed_tail = 0 if a.no_kernel_timer else min(5, a.steps)
-    timer = ops.KernelTimer(("conv_gemm", "wgrad_gemm") if a.time_wgrad else ("conv_gemm",)) if timed_tail else None
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        if timer is not None and i == a.steps - timed_tail:
-            ops.TIMER = timer
-        loss = step(a.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    ops.TIMER = None
-    tmax = torch.tensor([dt], device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
-    cnt = torch.cat(ranks_acc[-3:]).float()
+    dt, loss = timed(a.steps, a.warmup)                      # the contract number: K clean steps
+    cnt = torch.cat([c.to(dev) for c in ranks_acc[-3:]]).float()
     top10 = float((cnt < 10).float().mean())
     final_loss = float(loss.detach())
+
+    dt_sync = None
+    if not a.no_host_sync_leg:                               # same step with the reference loop's per-step host readbacks
+        n_sync = max(3, min(10, a.steps))
+        dt_sync, _ = timed(n_sync, a.warmup + a.steps, host_sync=True)
+        dt_sync /= n_sync
+
+    timer = None
+    if not a.no_kernel_timer and a.timer_steps > 0:          # roofline leg, outside the timed region
+        timer = ops.KernelTimer(("conv_gemm", "wgrad_gemm"))
+        fence()
+        ops.TIMER = timer
+        for i in range(a.timer_steps):
+            step(a.warmup + a.steps + 20 + i)
+        fence()
+        ops.TIMER = None
 
     if rank == 0:
         out = {
@@ -197,17 +303,22 @@ def main():
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}"},
             "top10_acc": round(top10, 4), "final_loss": round(final_loss, 4),
         }
+        if dt_sync is not None:
+            out["host_synced"] = {"value": round(B * world / dt_sync, 2), "ms_per_step": round(1e3 * dt_sync, 3),
+                                  "note": "same step with loss.item() and the ranks read back on the host every step (train.py:194-196)"}
         if timer is not None:
             summ = timer.summary()
             key = max(summ, key=lambda k: summ[k][2])             # dominant = most total time
             n, flops, ms = summ[key]
             ach = flops / (ms * 1e-3) / 1e12
+            traffic, src = pmc_traffic(a.dtype, key[2], key[3], key[0])
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_TFLOPS[a.dtype], 4),
-                               "traffic": pmc_traffic(a.dtype, key[2], key[3], key[0]),
+                               "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic, "traffic_source": src,
                                "kernel": f"{key[0]}<{key[1]},TILE={key[2]},KS={key[3]}>", "launches": n,
-                               "avg_us": round(1e3 * ms / n, 2)}
-            out["kernel_time_ms_per_step"] = {f"{k[0]}<{k[1]},{k[2]},{k[3]}>": round(v[2] / timed_tail, 3) for k, v in summ.items()}
+                               "avg_us": round(1e3 * ms / n, 2),
+                               "measured": f"HIP events around every launch in {a.timer_steps} extra steps after the timed region"}
+            out["kernel_time_ms_per_step"] = {f"{k[0]}<{k[1]},{k[2]},{k[3]}>": round(v[2] / a.timer_steps, 3) for k, v in summ.items()}
+            out["kernel_tflops"] = {f"{k[0]}<{k[1]},{k[2]},{k[3]}>": round(v[1] / (v[2] * 1e-3) / 1e12, 1) for k, v in summ.items() if v[2] > 0}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out), flush=True)

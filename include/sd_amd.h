@@ -7,9 +7,10 @@
  *     speech_decoding/models.py:111-117  SubjectBlock.forward          -> sda_conv_gemm (widx = subject)
  *     speech_decoding/models.py:152-166  ConvBlock.forward             -> sda_conv_gemm, sda_bn_*, sda_glu_*
  *     speech_decoding/models.py:191-196  BrainEncoder.forward          -> sda_conv_gemm (GELU epilogue)
- *     speech_decoding/utils/loss.py:58-79 CLIPLoss.forward (fast path) -> sda_rows_sumsq, sda_conv_gemm
- *                                                                         (split-K), sda_clip_ce, sda_wgrad_gemm
- *     speech_decoding/models.py:208-248  Classifier.forward            -> sda_clip_ce (ranks output)
+ *     speech_decoding/utils/loss.py:58-79 CLIPLoss.forward (fast path) -> sda_rows_sumsq, sda_conv_gemm (split-K),
+ *                                                                         sda_clip_logits_stats, sda_clip_grad,
+ *                                                                         sda_wgrad_gemm (typed output)
+ *     speech_decoding/models.py:208-248  Classifier.forward            -> sda_clip_ranks
  * and their autograd backward.  Every entry point takes plain device pointers, sizes and a
  * hipStream_t (passed as void*); no torch types cross this boundary.  All functions return 0 on
  * success and a negative code on failure; sda_last_error() gives the message.
@@ -31,7 +32,7 @@ extern "C" {
 #define SDA_ROW_PAD 16
 #define SDA_CH_ALIGN 64
 
-enum { SDA_F32 = 0, SDA_BF16 = 1 };
+enum { SDA_F32 = 0, SDA_BF16 = 1, SDA_F16 = 2 };   /* storage + MFMA operand type; accumulation is always fp32 */
 
 /* conv_gemm epilogue flags */
 enum { SDA_EPI_GELU = 1,

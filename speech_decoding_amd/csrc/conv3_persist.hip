@@ -386,6 +386,7 @@ int launch_persist(const sda_conv_args& a, hipStream_t st) {
 
 bool conv3_persist_supports(const sda_conv_args& a) {
   const int slab = ROW_B / (a.dtype == SDA_F32 ? 4 : 2);
+  if (a.dtype != SDA_F32 && a.dtype != SDA_BF16) return false;     // fp16 runs on the tile-per-workgroup kernel
   return a.KS == 3 && a.Cout_p % P_CO == 0 && !a.widx && a.ksplit == 1 && !a.partial && !(a.flags & SDA_EPI_GELU) &&
          !a.y_pre && a.y && a.Cin_p / slab >= 5 && (!a.bn_x || (a.bn_coef && a.stats));
 }

@@ -41,6 +41,9 @@ typedef __attribute__((address_space(3))) void lds_v;
 
 template <typename T> __device__ inline float4 round_like(float4 v);
 template <> __device__ inline float4 round_like<float>(float4 v) { return v; }
+template <> __device__ inline float4 round_like<half_t>(float4 v) {
+  return make_float4((float)(half_t)v.x, (float)(half_t)v.y, (float)(half_t)v.z, (float)(half_t)v.w);
+}
 template <> __device__ inline float4 round_like<uint16_t>(float4 v) {
   return make_float4(bf2f(f2bf(v.x)), bf2f(f2bf(v.y)), bf2f(f2bf(v.z)), bf2f(f2bf(v.w)));
 }
@@ -480,6 +483,7 @@ extern "C" int sda_conv_gemm(const sda_conv_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == SDA_F32) return dispatch_conv<float>(*a, st);
   if (a->dtype == SDA_BF16) return dispatch_conv<uint16_t>(*a, st);
+  if (a->dtype == SDA_F16) return dispatch_conv<half_t>(*a, st);
   set_error("conv_gemm: unknown dtype %d", a->dtype);
   return -1;
 }

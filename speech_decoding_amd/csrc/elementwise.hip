@@ -630,6 +630,7 @@ using namespace sda;
   do {                                                              \
     if ((dtype) == SDA_F32) { using E = float; CALL; }              \
     else if ((dtype) == SDA_BF16) { using E = uint16_t; CALL; }     \
+    else if ((dtype) == SDA_F16) { using E = half_t; CALL; }        \
     else { set_error("unknown dtype %d", (int)(dtype)); return -1; } \
   } while (0)
 
@@ -784,7 +785,6 @@ extern "C" int sda_bn_gelu_forward(const void* x, void* y, const float* scale, c
   return check_launch("bn_gelu_forward");
 }
 
-extern "C" int sda_bn_bwd_max_blocks(void) { return RED_MAX_BLOCKS; }
 
 extern "C" int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const float* mean, const float* rstd,
                                            const float* gamma, const float* beta, int C, float* partial, float* dgamma,
@@ -794,7 +794,7 @@ extern "C" int sda_bn_gelu_backward_reduce(const void* dy, const void* x, const 
   }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const int RG = 256 / (Cp / (dtype == SDA_BF16 ? 8 : 4));
+  const int RG = 256 / (Cp / (dtype == SDA_F32 ? 4 : 8));
   const size_t lds = (size_t)RG * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((col_reduce_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)dy,
                                          (const E*)x, mean, rstd, gamma, beta, C, partial, B, T, Cp));
@@ -847,7 +847,7 @@ extern "C" int sda_colsum(const void* x, float* out, float* scratch, int B, int 
   if (!x || !out || !scratch || Cp % 64 || Cp > 1024) { set_error("colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const int RG = 256 / (Cp / (dtype == SDA_BF16 ? 8 : 4));
+  const int RG = 256 / (Cp / (dtype == SDA_F32 ? 4 : 8));
   const size_t lds = (size_t)RG * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((col_reduce_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)x,
                                          (const E*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, B, T, Cp));
@@ -886,7 +886,7 @@ extern "C" int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, 
   if (!x || !dy || !dx || !colsum || !scratch || Ch % 64 || Ch > 1024) { set_error("glu_backward_colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const size_t lds = (size_t)(256 / (Ch / (dtype == SDA_BF16 ? 8 : 4))) * 2 * Ch * sizeof(float);
+  const size_t lds = (size_t)(256 / (Ch / (dtype == SDA_F32 ? 4 : 8))) * 2 * Ch * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)x,
                                          (const E*)dy, (E*)dx, scratch, B, T, Ch));
   hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
@@ -898,7 +898,7 @@ extern "C" int sda_gelu_backward_colsum(const void* u, const void* dz, void* du,
   if (!u || !dz || !du || !colsum || !scratch || Cp % 64 || Cp > 1024) { set_error("gelu_backward_colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const size_t lds = (size_t)(256 / (Cp / (dtype == SDA_BF16 ? 8 : 4))) * 2 * Cp * sizeof(float);
+  const size_t lds = (size_t)(256 / (Cp / (dtype == SDA_F32 ? 4 : 8))) * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)u,
                                          (const E*)dz, (E*)du, scratch, B, T, Cp));
   hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, (float*)nullptr, Cp);

@@ -269,6 +269,8 @@ extern "C" int sda_sa_weights_forward(const float* z, const float* cos_t, const 
     hipLaunchKernelGGL(sa_fwd_final_kernel<float>, dim3(D1p), dim3(256), 0, st, scratch, nchunk, C, mask, W, (float*)Wp, D1, C, Cp);
   else if (dtype == SDA_BF16)
     hipLaunchKernelGGL(sa_fwd_final_kernel<uint16_t>, dim3(D1p), dim3(256), 0, st, scratch, nchunk, C, mask, W, (uint16_t*)Wp, D1, C, Cp);
+  else if (dtype == SDA_F16)
+    hipLaunchKernelGGL(sa_fwd_final_kernel<half_t>, dim3(D1p), dim3(256), 0, st, scratch, nchunk, C, mask, W, (half_t*)Wp, D1, C, Cp);
   else { set_error("sa_weights_forward: unknown dtype"); return -1; }
   return check_launch("sa_weights_forward");
 }
@@ -284,6 +286,8 @@ extern "C" int sda_sa_softmax_pack(const float* a, int a_pitch, const float* mas
     hipLaunchKernelGGL(sa_fwd_final_kernel<float>, dim3(D1p), dim3(256), 0, st, a, 1, a_pitch, mask, W, (float*)Wp, D1, C, Cp);
   else if (dtype == SDA_BF16)
     hipLaunchKernelGGL(sa_fwd_final_kernel<uint16_t>, dim3(D1p), dim3(256), 0, st, a, 1, a_pitch, mask, W, (uint16_t*)Wp, D1, C, Cp);
+  else if (dtype == SDA_F16)
+    hipLaunchKernelGGL(sa_fwd_final_kernel<half_t>, dim3(D1p), dim3(256), 0, st, a, 1, a_pitch, mask, W, (half_t*)Wp, D1, C, Cp);
   else { set_error("sa_softmax_pack: unknown dtype"); return -1; }
   return check_launch("sa_softmax_pack");
 }
@@ -327,6 +331,8 @@ extern "C" int sda_clip_grad(const float* logits, const float* row_lse, const fl
     hipLaunchKernelGGL(clip_grad_kernel<float>, dim3(Bn), dim3(256), 0, st, logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, (float*)G, g_pitch, rscale, colpart, Bm, Bn);
   else if (dtype == SDA_BF16)
     hipLaunchKernelGGL(clip_grad_kernel<uint16_t>, dim3(Bn), dim3(256), 0, st, logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, (uint16_t*)G, g_pitch, rscale, colpart, Bm, Bn);
+  else if (dtype == SDA_F16)
+    hipLaunchKernelGGL(clip_grad_kernel<half_t>, dim3(Bn), dim3(256), 0, st, logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, (half_t*)G, g_pitch, rscale, colpart, Bm, Bn);
   else { set_error("clip_grad: unknown dtype"); return -1; }
   hipLaunchKernelGGL(clip_scalars_kernel, dim3(1), dim3(64), 0, st, colpart, inv_norm, scalars, Bn);
   return check_launch("clip_grad");

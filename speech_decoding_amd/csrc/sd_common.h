@@ -25,6 +25,9 @@ __host__ __device__ inline long rows_alloc(int B, int T) { return (long)B * rows
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef _Float16 half_t;                                    // fp16 storage element (bf16 storage is uint16_t)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 // bf16 <-> f32 (round to nearest even; NaN stays NaN through the compiler's cvt)
 __device__ inline float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -33,7 +36,19 @@ __device__ inline uint16_t f2bf(float f) {
   return *reinterpret_cast<uint16_t*>(&b);
 }
 
-// Element traits: E = float (exact fp32 path on the f32 MFMA) or uint16_t (bf16 storage).
+// two fp16 values packed in one register <-> floats (v_cvt_f32_f16 / v_cvt_f16_f32, round to nearest even)
+__device__ inline float2 h2_to_f2(uint32_t w) {
+  const f16x2 h = __builtin_bit_cast(f16x2, w);
+  return make_float2((float)h[0], (float)h[1]);
+}
+__device__ inline uint32_t f2_to_h2(float a, float b) {
+  f16x2 h;
+  h[0] = (_Float16)a;
+  h[1] = (_Float16)b;
+  return __builtin_bit_cast(uint32_t, h);
+}
+
+// Element traits: E = float (exact fp32 path on the f32 MFMA), uint16_t (bf16 storage) or half_t (fp16 storage).
 template <typename E> struct Elem;
 template <> struct Elem<float> {
   static constexpr int PER16 = 4;      // elements per 16-byte chunk
@@ -48,6 +63,13 @@ template <> struct Elem<uint16_t> {
   __device__ static void st(uint16_t* p, float v) { *p = f2bf(v); }
 };
 
+template <> struct Elem<half_t> {
+  static constexpr int PER16 = 8;
+  static constexpr int SLAB = 64;
+  __device__ static float ld(const half_t* p) { return (float)*p; }
+  __device__ static void st(half_t* p, float v) { *p = (half_t)v; }
+};
+
 // 4 consecutive elements <-> float4 (16-byte fp32 / 8-byte bf16 accesses)
 __device__ inline float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ inline float4 load4(const uint16_t* p) {
@@ -60,6 +82,18 @@ __device__ inline void store4(uint16_t* p, float4 v) {
   uint2 u;
   u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
   u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+__device__ inline float4 load4(const half_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  const float2 a = h2_to_f2(u.x), b = h2_to_f2(u.y);
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ inline void store4(half_t* p, float4 v) {
+  uint2 u;
+  u.x = f2_to_h2(v.x, v.y);
+  u.y = f2_to_h2(v.z, v.w);
   *reinterpret_cast<uint2*>(p) = u;
 }
 
@@ -102,6 +136,21 @@ template <> struct Vec16<uint16_t> {
   }
 };
 
+template <> struct Vec16<half_t> {
+  static constexpr int N = 8;
+  __device__ static void unpack(const uint4& u, float* v) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float2 f = h2_to_f2(w[i]); v[2 * i] = f.x; v[2 * i + 1] = f.y; }
+  }
+  __device__ static void load(const half_t* p, float* v) { unpack(*reinterpret_cast<const uint4*>(p), v); }
+  __device__ static void store(half_t* p, const float* v) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(f2_to_h2(v[0], v[1]), f2_to_h2(v[2], v[3]), f2_to_h2(v[4], v[5]), f2_to_h2(v[6], v[7]));
+  }
+  __device__ static float round(float x) { return (float)(half_t)x; }
+  __device__ static uint4 load_raw(const half_t* p) { return *reinterpret_cast<const uint4*>(p); }
+};
+
 // Byte offset of 16-byte chunk `chunk` (0..7) of 128-byte LDS row `row`, XOR-swizzled so that 16
 // lanes reading the same chunk of 16 consecutive rows (the MFMA operand pattern) hit 16 distinct
 // 16-byte slots of the 256-byte bank row.
@@ -114,6 +163,9 @@ template <typename E> __device__ inline f32x4 mma16(const uint4& a, const uint4&
 template <> __device__ inline f32x4 mma16<uint16_t>(const uint4& a, const uint4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const s16x8*>(&a),
                                                  *reinterpret_cast<const s16x8*>(&b), c, 0, 0, 0);
+}
+template <> __device__ inline f32x4 mma16<half_t>(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
 }
 template <> __device__ inline f32x4 mma16<float>(const uint4& a, const uint4& b, f32x4 c) {
   c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -156,6 +208,10 @@ template <> __device__ inline float gelu_grad_f<uint16_t>(float x) {
   normal_cdf_pdf(x, cdf, pdf);
   return fmaf(x, pdf, cdf);
 }
+// fp16 storage: the same shared-exp form (its 1.5e-7 absolute error is below half an fp16 ulp for |GELU| > 3e-4 and
+// below the smallest normal fp16 step elsewhere)
+template <> __device__ inline float gelu_f<half_t>(float x) { return gelu_f<uint16_t>(x); }
+template <> __device__ inline float gelu_grad_f<half_t>(float x) { return gelu_grad_f<uint16_t>(x); }
 __device__ inline float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __device__ inline float wave_sum(float v) {

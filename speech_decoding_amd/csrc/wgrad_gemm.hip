@@ -20,6 +20,7 @@ namespace sda {
 // Rows per MFMA K-step: 32 (bf16) / 16 (fp32).  A staged K-chunk holds KM of them.
 template <typename E> struct WK;
 template <> struct WK<uint16_t> { static constexpr int KSTEP = 32; };
+template <> struct WK<half_t> { static constexpr int KSTEP = 32; };
 template <> struct WK<float> { static constexpr int KSTEP = 16; };
 
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the immediate must be a literal); anything above the
@@ -86,6 +87,9 @@ template <int RB> __device__ inline uint4 tr_operand_f32(const unsigned char* im
 }
 template <typename E, int RB> struct TrOp;
 template <int RB> struct TrOp<uint16_t, RB> {
+  __device__ static uint4 get(const unsigned char* img, int row0, int col0, int lane) { return tr_operand_bf16<RB>(img, row0, col0, lane); }
+};
+template <int RB> struct TrOp<half_t, RB> {     // any 16-bit element: ds_read_b64_tr_b16 moves bits
   __device__ static uint4 get(const unsigned char* img, int row0, int col0, int lane) { return tr_operand_bf16<RB>(img, row0, col0, lane); }
 };
 template <int RB> struct TrOp<float, RB> {
@@ -328,6 +332,7 @@ extern "C" int sda_wgrad_gemm(const sda_wgrad_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == SDA_F32) return dispatch_wgrad<float>(*a, st);
   if (a->dtype == SDA_BF16) return dispatch_wgrad<uint16_t>(*a, st);
+  if (a->dtype == SDA_F16) return dispatch_wgrad<half_t>(*a, st);
   set_error("wgrad_gemm: unknown dtype %d", a->dtype);
   return -1;
 }

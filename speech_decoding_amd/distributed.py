@@ -11,6 +11,7 @@ What shards and what is exchanged:
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List
 
 import torch
@@ -18,6 +19,18 @@ import torch.distributed as dist
 
 
 _side_groups = {}
+
+
+def active_group():
+    """The process group the data-parallel paths use: WORLD when torch.distributed is initialised with more than one
+    rank, else None (single-process code path, no collectives).  SDA_DP_SINGLE_RANK=1 keeps the data-parallel path
+    on even at world size 1 — every collective then runs through the backend with one rank (the RCCL call sequence
+    can be exercised on a one-GPU box; results equal the single-process path)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_world_size() > 1 or os.environ.get("SDA_DP_SINGLE_RANK") == "1":
+        return dist.group.WORLD
+    return None
 
 
 def side_group(name: str, group=None):
@@ -28,7 +41,8 @@ def side_group(name: str, group=None):
     BatchNorm-statistics all-reduce.  The bulk collectives therefore get communicators of their own ("gather",
     "grads").  Every rank must reach the first call for a name at the same point of the program (it is a
     collective): the callers create it on their first collective of that kind, which all ranks issue together."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1
+                                                               and os.environ.get("SDA_DP_SINGLE_RANK") != "1"):
         return group
     key = (name, id(group) if group is not None else 0)
     g = _side_groups.get(key)
@@ -51,7 +65,7 @@ def _flat_views(params: Iterable[torch.nn.Parameter]) -> List[torch.Tensor]:
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):
     """SUM all-reduce of every parameter gradient in flat fp32 buckets (few large collectives: xGMI rings
     are per-link bound, so fewer, larger messages win)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if active_group() is None and group is None:
         return
     views = _flat_views(list(params))
     bucket, size = [], 0
@@ -96,7 +110,7 @@ def merge_row_softmax_stats(row_max: torch.Tensor, row_sum: torch.Tensor, group=
     and merged locally in rank order — the small collectives of a step are latency-bound, so they are packed.
     With `diag` (each rank's positives' logits, zero where the positive lives elsewhere) returns
     (lse, diag summed over ranks)."""
-    if group is not None and dist.is_initialized() and dist.get_world_size(group) > 1:     # None = stay local
+    if group is not None and dist.is_initialized():     # None = stay local
         world = dist.get_world_size(group)
         parts = [row_max, row_sum] + ([diag] if diag is not None else [])
         mine = torch.stack([p.to(torch.float32) for p in parts]).contiguous()             # (k, Bg)

@@ -74,8 +74,10 @@ class EncoderEngine:
         self.overlap_grad_allreduce = True   # under DP: SUM all-reduce each layer group's gradients as soon as
                                              # they exist, on RCCL's stream, overlapped with the rest of backward
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._ws_shapes: List[tuple] = []    # (space, B, T) groups in least-recently-used order
+        self.max_workspace_shapes = 2        # per space: a ragged last batch gets a second set, a third shape evicts the oldest
         self._seg_cache: Dict[tuple, tuple] = {}
-        self._gen = 0
+        self._gen = 0                        # generation of the TRAIN workspace (bumped by grad-mode forwards only)
         self.reuse_workspace = True
         self.fuse_bn_backward_stats = True   # BatchNorm-backward sums in the data-gradient conv's epilogue
         self.wgrad_target_wgs = 256          # workgroups per weight-gradient launch (split over sample segments)
@@ -108,8 +110,25 @@ class EncoderEngine:
             self._ws[key] = buf
         return buf
 
+    def _touch_shape(self, space: str, B: int, T: int):
+        """LRU over (space, B, T) buffer sets: a training run sees one batch shape plus, with drop_last=False, one
+        ragged last batch; anything beyond `max_workspace_shapes` per space releases the least recently used set
+        (a pending backward keeps its own buffers alive through its ctx)."""
+        g = (space, B, T)
+        if g in self._ws_shapes:
+            self._ws_shapes.remove(g)
+        self._ws_shapes.append(g)
+        mine = [x for x in self._ws_shapes if x[0] == space]
+        while len(mine) > self.max_workspace_shapes:
+            old = mine.pop(0)
+            self._ws_shapes.remove(old)
+            for k in [k for k in self._ws if (k[0], k[2], k[3]) == old]:
+                del self._ws[k]
+
     def release_workspace(self):
         self._ws.clear()
+        self._ws_shapes.clear()
+        self._seg_cache.clear()
 
     def _uniform_segments(self, B: int, ntiles: int, device):
         # segments are dealt round-robin to the 8 XCDs (wgrad_gemm's block order), so use a multiple of 8
@@ -162,8 +181,10 @@ class EncoderEngine:
         B, Cc, T = X.shape
         assert Cc == d.C, f"expected {d.C} channels, got {Cc}"          # models.py:78
         dev = X.device
-        self._gen += 1
         space = "train" if need_grad else "eval"
+        if need_grad:                    # no-grad forwards live in the "eval" buffers: they leave a pending backward intact
+            self._gen += 1
+        self._touch_shape(space, B, T)
         ctx = EncoderCtx(B=B, T=T, gen=self._gen, training=training)
         bufs, pk = ctx.bufs, ctx.packed
 
@@ -257,7 +278,7 @@ class EncoderEngine:
                     ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, stats=stats, alg_dims=alg,
                                   flags=k3_flags)
                     nt = ntile
-                    if world > 1:                # one 2*Cp-float all-reduce per BatchNorm
+                    if self.group is not None:   # one 2*Cp-float all-reduce per BatchNorm
                         stats = ops.reduce_slabs(stats).reshape(1, 2, d.D2p)
                         self._allreduce(stats)
                         nt = 1
@@ -283,7 +304,9 @@ class EncoderEngine:
         u1, g1 = rows("u1", d.F1p), rows("g1", d.F1p)
         ops.conv_gemm(x, pk["f1w"], g1, B=B, T=T, KS=1, dil=0, bias=pk["f1b"], y_pre=u1 if need_grad else None,
                       gelu=True, alg_dims=(d.D2, d.F1))
-        u2, Zt = rows("u2", d.Fp), self._rows("Z", B, T, d.Fp, dev, space)
+        # Z is handed to the caller: a FRESH buffer per forward (the reference returns a new tensor each call), so
+        # embeddings kept across forwards stay valid; everything else lives in the reused workspace
+        u2, Zt = rows("u2", d.Fp), ops.new_rows_uninit(B, T, d.Fp, dt, dev)
         zstats = torch.empty((B * ops.n_t_tiles(T), 2, d.Fp), dtype=torch.float32, device=dev)
         ops.conv_gemm(g1, pk["f2w"], Zt, B=B, T=T, KS=1, dil=0, bias=pk["f2b"], y_pre=u2 if need_grad else None,
                       gelu=True, stats=zstats, alg_dims=(d.F1, d.F))
@@ -309,7 +332,7 @@ class EncoderEngine:
         grads: Dict[str, torch.Tensor] = {}
         scratch = ops.reduce_scratch(max(d.Fp, 2 * d.D2p, d.F1p), dev)
         pending = []                          # (work, names) of in-flight gradient all-reduces
-        overlap = self.world > 1 and self.overlap_grad_allreduce
+        overlap = self.group is not None and self.overlap_grad_allreduce
 
         def flush(names):
             """Pack the named gradients into one flat bucket, start its SUM all-reduce asynchronously and
@@ -435,9 +458,9 @@ class EncoderEngine:
                 world = self.world
                 dgam, dbet = ops.bn_gelu_backward(da1, bufs[f"b{k}.h{j}"], mean, rstd, P[bnp + "w"], P[bnp + "b"], dh, B, T,
                                                   scratch, count=float(B) * T * world,
-                                                  allreduce=self._allreduce if world > 1 else None, tile_stats=tstats)
+                                                  allreduce=self._allreduce if self.group is not None else None, tile_stats=tstats)
                 # under DP the sums are already global on every rank; the gradient all-reduce (SUM) follows
-                if world > 1:
+                if self.group is not None:
                     dgam, dbet = dgam / world, dbet / world
                 grads[bnp + "w"], grads[bnp + "b"] = dgam[: d.D2], dbet[: d.D2]
                 src = bufs[f"b{k}.a0"] if j == 1 else x_in
@@ -516,6 +539,13 @@ class ClipCtx:
     Zt: torch.Tensor
     row_elems: int
     dtemp: torch.Tensor
+    g_scale: float = 1.0          # power of two folded into G / rscale (fp16 only), divided out of the embedding gradient
+
+
+# dL/dlogits * exp(temp) / (|Y||Z|) is ~1e-5 at the training shapes: inside fp16's subnormal range.  The coefficient
+# matrix G (an MFMA operand, so it has to be 16-bit) is stored multiplied by this power of two and the factor is taken
+# out again in the fp32 epilogue of the dZ GEMM — exact, invisible to the caller.
+G_PRESCALE = {torch.float16: 4096.0}
 
 
 def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: int, Bn: int, T: int, col0: int = 0,
@@ -538,13 +568,19 @@ def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: 
     row_lse, diag = merge_row_softmax_stats(row_max, row_sum, dist_group, diag=diag)   # diag: zero where not owned
     Bg = B_global if B_global is not None else Bm
     inv_norm = 1.0 / (2.0 * Bg) if reduction == "mean" else 0.5
-    G, rscale, scalars = ops.clip_grad(logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, Yt.dtype)
+    gs = G_PRESCALE.get(Yt.dtype, 1.0)
+    G, rscale, scalars = ops.clip_grad(logits, row_lse, col_lse, ysq, zsq, temp, inv_norm * gs, col0, Yt.dtype)
+    if gs != 1.0:
+        scalars = scalars * (1.0 / gs)
     cnt = ops.clip_ranks(logits, diag, col0)
-    ctx = ClipCtx(Bm=Bm, Bn=Bn, col0=col0, G=G, rscale=rscale, Yt=Yt, Zt=Zt, row_elems=row_elems, dtemp=scalars[1:2])
+    ctx = ClipCtx(Bm=Bm, Bn=Bn, col0=col0, G=G, rscale=rscale, Yt=Yt, Zt=Zt, row_elems=row_elems, dtemp=scalars[1:2],
+                  g_scale=gs)
     return scalars[0:1], logits, cnt, ctx
 
 
 def clip_backward(ctx: ClipCtx, dZt: torch.Tensor, dloss: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dZ = dloss * (G^T Y - diag(r) Z)  (gradient of the loss share w.r.t. the local brain embeddings)."""
+    if ctx.g_scale != 1.0:
+        dloss = (dloss if dloss is not None else torch.ones(1, dtype=torch.float32, device=dZt.device)) * (1.0 / ctx.g_scale)
     return ops.matmul_tn_typed(ctx.G, ctx.Yt, dZt, ctx.Zt, ctx.rscale, M_rows=ctx.Bm, N_valid=ctx.Bn,
                                K_cols=ctx.row_elems, pitch=ctx.row_elems, out_scale=dloss)

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdamd.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ROW_PAD = 16
 CH_ALIGN = 64
 EPI_GELU = 1

@@ -19,8 +19,37 @@ from . import engine as E
 
 import weakref
 
-_rank_cache = []          # [(weakref(Y), weakref(Z), ranks)] from the last CLIPLoss forward
-_dz_cache = {}            # (B, F, T, dtype, device) -> persistent RL buffer for dL/dZ
+_rank_cache = []          # [(weakref(Y), weakref(Z), ranks)] from the last CLIPLoss forward (keyed by tensor IDENTITY)
+
+
+class LossState:
+    """Buffers that outlive one call, owned by ONE CLIPLoss instance (nothing is shared between instances by shape):
+    the rotating packed-speech buffers and the pending speech-side prefetch.  Every hand-out of a ring slot bumps
+    that slot's generation; a backward checks the generation it was given, so a buffer recycled by later forwards
+    raises instead of silently feeding another batch's rows into the gradient."""
+
+    def __init__(self):
+        self.rings = {}           # (key, B, C, T, dtype, device) -> [buffers, next index, generations]
+        self.prefetched = []      # at most one pending prefetch
+        self.ring_depth = 2
+
+    def clear(self):
+        self.rings.clear()
+        self.prefetched.clear()
+
+
+_DEFAULT_STATE = LossState()      # for the module-level helpers called without a CLIPLoss instance
+
+
+class RingSlot:
+    """A ring buffer handed out at generation `gen`; valid() is False once the slot has been handed out again."""
+    __slots__ = ("ring", "idx", "gen", "buf")
+
+    def __init__(self, ring, idx, gen, buf):
+        self.ring, self.idx, self.gen, self.buf = ring, idx, gen, buf
+
+    def valid(self) -> bool:
+        return self.ring[2][self.idx] == self.gen
 
 
 def _cache_ranks(Y, Z, cnt):
@@ -48,73 +77,78 @@ def _rows_base(t: torch.Tensor, B: int, Cc: int, T: int, dtype):
     return t.detach().as_strided((rows, Cp), (Cp, 1), 0)
 
 
-_pack_ring = {}           # (slot key, B, C, T, dtype, device) -> [buffers], next index
-
-
-def _ring_rows(key, B, Cc, T, dtype, device, depth=2):
-    """Persistent RL buffers for packed inputs (no per-call 200 MB allocation + memset).  `depth` buffers
+def _ring_rows(state: LossState, key, B, Cc, T, dtype, device) -> RingSlot:
+    """Persistent RL buffers for packed inputs (no per-call 200 MB allocation + memset).  `ring_depth` buffers
     rotate so that the buffer a pending backward still needs survives one further forward (e.g. an eval
-    pass between forward and backward)."""
+    pass between forward and backward); a backward that comes later than that finds its slot's generation changed."""
     k = (key, B, Cc, T, dtype, str(device))
-    ring = _pack_ring.get(k)
+    ring = state.rings.get(k)
     if ring is None:
-        ring = _pack_ring[k] = [[ops.new_rows(B, T, L.pad_channels(Cc), dtype, device) for _ in range(depth)], 0]
-    buf = ring[0][ring[1] % depth]
+        if len(state.rings) >= 8:                  # ragged last batches etc.: keep the most recent shapes only
+            state.rings.pop(next(iter(state.rings)))
+        depth = state.ring_depth
+        ring = state.rings[k] = [[ops.new_rows(B, T, L.pad_channels(Cc), dtype, device) for _ in range(depth)], 0, [0] * depth]
+    idx = ring[1] % len(ring[0])
     ring[1] += 1
-    return buf
+    ring[2][idx] += 1
+    return RingSlot(ring, idx, ring[2][idx], ring[0][idx])
 
 
-def as_rows(t: torch.Tensor, B: int, Cc: int, T: int, dtype, name: str, ring_key=None) -> torch.Tensor:
+def as_rows(t: torch.Tensor, B: int, Cc: int, T: int, dtype, name: str, ring_key=None, state: Optional[LossState] = None,
+            want_slot: bool = False):
     """Return the RL buffer behind `t` (zero copy when `t` is a rows_view made by this package), else
-    pack a plain (B, C, T) tensor into an RL buffer (a rotating persistent one when `ring_key` is given)."""
+    pack a plain (B, C, T) tensor into an RL buffer (a rotating persistent one of `state` when `ring_key` is given).
+    With want_slot: (buffer, RingSlot or None)."""
     if tuple(t.shape) != (B, Cc, T):
         raise ValueError(f"{name}: expected shape {(B, Cc, T)}, got {tuple(t.shape)}")
     base = _rows_base(t, B, Cc, T, dtype)
     if base is not None:
-        return base
+        return (base, None) if want_slot else base
     if not t.is_cuda:
         raise L.SdaError(f"{name} must live on the MI355X device (there is no CPU path)")
+    slot = None
     if ring_key is not None:
-        buf = _ring_rows(ring_key, B, Cc, T, dtype, t.device)       # pack_rows rewrites every valid row
+        slot = _ring_rows(state or _DEFAULT_STATE, ring_key, B, Cc, T, dtype, t.device)   # pack_rows rewrites every valid row
+        buf = slot.buf
     else:
         buf = ops.new_rows(B, T, L.pad_channels(Cc), dtype, t.device)
     ops.pack_rows(t.detach().float().contiguous(), buf)
-    return buf
+    return (buf, slot) if want_slot else buf
 
 
 def _dist_group():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist.group.WORLD
-    return None
+    from .distributed import active_group
+    return active_group()
 
 
-def gather_speech_rows(Yt_local: torch.Tensor, B: int, T: int, group, async_op: bool = False):
+def gather_speech_rows(Yt_local: torch.Tensor, B: int, T: int, group, async_op: bool = False,
+                       state: Optional[LossState] = None, slot: Optional[RingSlot] = None):
     """All-gather the packed speech rows of every rank (RCCL all_gather over xGMI; samples are contiguous
     blocks of Tp rows, so the gather lands directly in RL order) together with their squared norms (computed
-    once, on the rank that owns the rows).  Returns (Yt, ysq, Bm, col0, B_global, works)."""
+    once, on the rank that owns the rows).  Returns (Yt, ysq, Bm, col0, B_global, works, slot): `slot` is the ring
+    slot that owns the rows the backward will read (the local pack without a group, the gathered buffer with one)."""
     row_elems = L.rows_tp(T) * Yt_local.shape[1]
     ysq_local = ops.rows_sumsq(Yt_local, B, row_elems, row_elems)
     if group is None:
-        return Yt_local, ysq_local, B, 0, B, []
+        return Yt_local, ysq_local, B, 0, B, [], slot
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     Tp = L.rows_tp(T)
-    Yt = _ring_rows("loss.Yall", B * world, Yt_local.shape[1], T, Yt_local.dtype, Yt_local.device)
+    slot = _ring_rows(state or _DEFAULT_STATE, "loss.Yall", B * world, Yt_local.shape[1], T, Yt_local.dtype, Yt_local.device)
+    Yt = slot.buf
     ysq = torch.empty(B * world, dtype=torch.float32, device=Yt_local.device)
     from .distributed import side_group
     bulk = side_group("gather", group)          # own communicator: must not queue in front of the BatchNorm all-reduces
     w1 = dist.all_gather_into_tensor(Yt[: B * world * Tp], Yt_local[: B * Tp], group=bulk, async_op=async_op)
     w2 = dist.all_gather_into_tensor(ysq, ysq_local, group=bulk, async_op=async_op)
-    return Yt, ysq, B * world, rank * B, B * world, ([w1, w2] if async_op else [])
+    return Yt, ysq, B * world, rank * B, B * world, ([w1, w2] if async_op else []), slot
 
 
-_prefetched = []          # [(weakref(Y), dtype, Yt, ysq, Bm, col0, Bg, works, done_event)] — at most one pending prefetch
 _prefetch_streams = {}    # device -> side stream the speech-side work runs on
 PREFETCH_ON_SIDE_STREAM = True
 
 
-def prefetch_speech(Y: torch.Tensor, dtype=None, global_negatives: bool = True):
+def prefetch_speech(Y: torch.Tensor, dtype=None, global_negatives: bool = True, state: Optional[LossState] = None):
     """Start the speech-side work of the loss EARLY: pack Y into row layout, take its row norms and, under data
     parallelism, launch the all-gather of the packed rows asynchronously on RCCL's stream.  Y does not depend on
     the encoder, so calling this before `brain_encoder(X, ...)` hides the 1.4 GB (8 GPUs, config 3) gather behind
@@ -122,6 +156,7 @@ def prefetch_speech(Y: torch.Tensor, dtype=None, global_negatives: bool = True):
     encoder's first layers instead of in front of them."""
     B, F, T = Y.shape
     dtype = dtype or torch.float32
+    state = state or _DEFAULT_STATE
     group = _dist_group() if global_negatives else None
     done = None
     if PREFETCH_ON_SIDE_STREAM and Y.is_cuda:
@@ -133,27 +168,27 @@ def prefetch_speech(Y: torch.Tensor, dtype=None, global_negatives: bool = True):
         ev.record(main)
         side.wait_event(ev)                       # Y itself, and the previous user of the ring buffer, are on `main`
         with torch.cuda.stream(side):
-            Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y")
-            Yt, ysq, Bm, col0, Bg, works = gather_speech_rows(Yt_local, B, T, group, async_op=True)
+            Yt_local, slot = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y", state=state, want_slot=True)
+            Yt, ysq, Bm, col0, Bg, works, slot = gather_speech_rows(Yt_local, B, T, group, async_op=True, state=state, slot=slot)
             done = torch.cuda.Event()
             done.record(side)
         ysq.record_stream(main)
     else:
-        Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y")
-        Yt, ysq, Bm, col0, Bg, works = gather_speech_rows(Yt_local, B, T, group, async_op=True)
-    _prefetched.clear()
-    _prefetched.append((weakref.ref(Y), dtype, Yt, ysq, Bm, col0, Bg, works, done))
+        Yt_local, slot = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y", state=state, want_slot=True)
+        Yt, ysq, Bm, col0, Bg, works, slot = gather_speech_rows(Yt_local, B, T, group, async_op=True, state=state, slot=slot)
+    state.prefetched.clear()
+    state.prefetched.append((weakref.ref(Y), dtype, Yt, ysq, Bm, col0, Bg, works, done, slot))
 
 
-def _take_prefetched(Y, dtype):
-    for wy, dt, Yt, ysq, Bm, col0, Bg, works, done in _prefetched:
+def _take_prefetched(state: LossState, Y, dtype):
+    for wy, dt, Yt, ysq, Bm, col0, Bg, works, done, slot in state.prefetched:
         if wy() is Y and dt == dtype:
-            _prefetched.clear()
+            state.prefetched.clear()
             if done is not None:
                 torch.cuda.current_stream(Yt.device).wait_event(done)
             for work in works:
                 work.wait()                     # current stream waits for RCCL's stream; the host does not block
-            return Yt, ysq, Bm, col0, Bg
+            return Yt, ysq, Bm, col0, Bg, slot
     return None
 
 
@@ -162,15 +197,19 @@ class _ClipFn(torch.autograd.Function):
     def forward(ctx, module: "CLIPLoss", Y, Z, temp):
         import torch.distributed as dist
         B, F, T = Z.shape
-        dtype = Z.dtype if Z.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        if Y.requires_grad:
+            raise L.SdaError("CLIPLoss: the speech embeddings (first argument) are data on this path and get no gradient "
+                             "(train.py:191 passes precomputed wav2vec2 features); detach them")
+        dtype = Z.dtype if Z.dtype in ops.COMPUTE_DTYPES else torch.float32
         Zt = as_rows(Z, B, F, T, dtype, "y (brain embeddings)")
         group = _dist_group() if module.global_negatives else None
-        pre = _take_prefetched(Y, dtype)
+        state = module._state
+        pre = _take_prefetched(state, Y, dtype)
         if pre is not None:
-            Yt, ysq, Bm, col0, Bg = pre
+            Yt, ysq, Bm, col0, Bg, slot = pre
         else:
-            Yt_local = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y")
-            Yt, ysq, Bm, col0, Bg, _ = gather_speech_rows(Yt_local, B, T, group)
+            Yt_local, slot = as_rows(Y, B, F, T, dtype, "x (speech embeddings)", ring_key="loss.Y", state=state, want_slot=True)
+            Yt, ysq, Bm, col0, Bg, _, slot = gather_speech_rows(Yt_local, B, T, group, state=state, slot=slot)
         loss, logits, cnt, cctx = E.clip_forward(Yt, Zt, temp.detach(), Bm=Bm, Bn=B, T=T, col0=col0,
                                                  reduction=module.reduction, B_global=Bg, dist_group=group, ysq=ysq)
         if group is not None:
@@ -180,6 +219,7 @@ class _ClipFn(torch.autograd.Function):
             dist.all_reduce(both, group=group)
             cnt, loss = both[:-1].round().to(torch.int32), both[-1:]
         ctx.cctx, ctx.shape, ctx.dtype, ctx.group = cctx, (B, F, T), dtype, group
+        ctx.y_slot = slot
         ctx.z_requires_grad = Z.requires_grad
         _cache_ranks(Y, Z, cnt[col0: col0 + B])
         ctx.mark_non_differentiable(logits)
@@ -192,11 +232,14 @@ class _ClipFn(torch.autograd.Function):
         dZ = None
         scale = dloss.to(torch.float32)
         if ctx.z_requires_grad:
-            # persistent dZ buffer: the kernel rewrites every valid row (pad rows get exact zeros), so no memset
-            key = (B, F, T, ctx.dtype, str(c.Zt.device))
-            dZt = _dz_cache.get(key)
-            if dZt is None:
-                dZt = _dz_cache[key] = ops.new_rows(B, T, c.Zt.shape[1], ctx.dtype, c.Zt.device)
+            if ctx.y_slot is not None and not ctx.y_slot.valid():
+                raise L.SdaError("CLIPLoss.backward: the packed speech rows of this forward were recycled by later forwards "
+                                 "of the same CLIPLoss (more than `ring_depth` forwards before this backward); raise "
+                                 "loss_func._state.ring_depth or call backward earlier")
+            # a buffer of its own per backward (two pending backwards must not share one): the GEMM rewrites every sample's
+            # rows, pad rows included (exact zeros), so only the slack behind the last sample needs a fill
+            dZt = torch.empty((L.rows_alloc(B, T), c.Zt.shape[1]), dtype=ctx.dtype, device=c.Zt.device)
+            dZt[B * L.rows_tp(T):].zero_()
             E.clip_backward(c, dZt, scale.reshape(1).contiguous())     # dloss folded into the GEMM epilogue
             dZ = ops.rows_view(dZt, B, F, T)
         dtemp = (c.dtemp * scale).reshape(1)
@@ -213,10 +256,15 @@ class CLIPLoss(nn.Module):
         self.temp = nn.Parameter(torch.tensor([float(args.init_temperature)]))
         self.global_negatives = True
         self.last_logits: Optional[torch.Tensor] = None
+        self._state = LossState()           # packed-speech ring + pending prefetch of THIS instance
 
     def prefetch(self, x: torch.Tensor, compute_dtype=torch.float32):
         """Optional: call with the speech embeddings BEFORE running the encoder (see prefetch_speech)."""
-        prefetch_speech(x, compute_dtype, self.global_negatives)
+        prefetch_speech(x, compute_dtype, self.global_negatives, state=self._state)
+
+    def release_buffers(self):
+        """Drop the persistent packed-speech buffers (e.g. between a training and an evaluation phase)."""
+        self._state.clear()
 
     def forward(self, x, y, fast=True, return_logits=False):
         batch_size = x.size(0)
@@ -239,12 +287,12 @@ def retrieval_ranks(Y: torch.Tensor, Z: torch.Tensor, global_candidates: bool = 
     if hit is not None:
         return hit
     B, F, T = Z.shape
-    dtype = Z.dtype if Z.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    dtype = Z.dtype if Z.dtype in ops.COMPUTE_DTYPES else torch.float32
     Zt = as_rows(Z, B, F, T, dtype, "Z")
     Yt = as_rows(Y, B, F, T, dtype, "Y")
     temp = torch.zeros(1, dtype=torch.float32, device=Zt.device)
     group = _dist_group() if global_candidates else None     # under data parallelism: the GLOBAL batch
-    Yt, ysq, Bm, col0, Bg, _ = gather_speech_rows(Yt, B, T, group)
+    Yt, ysq, Bm, col0, Bg, _, _ = gather_speech_rows(Yt, B, T, group)
     _, _, cnt, _ = E.clip_forward(Yt, Zt, temp, Bm=Bm, Bn=B, T=T, col0=col0, B_global=Bg, dist_group=group, ysq=ysq)
     if group is not None:
         import torch.distributed as dist

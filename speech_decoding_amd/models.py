@@ -34,14 +34,14 @@ def resolve_dtype(args) -> torch.dtype:
         return torch.float32
     if name in ("bf16", "bfloat16"):
         return torch.bfloat16
-    raise ValueError(f"compute_dtype must be fp32 or bf16, got {name!r}")
+    if name in ("fp16", "float16", "half", "f16"):
+        return torch.float16
+    raise ValueError(f"compute_dtype must be fp32, bf16 or fp16, got {name!r}")
 
 
 def _dp_group():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist.group.WORLD
-    return None
+    from .distributed import active_group
+    return active_group()
 
 
 class SpatialAttention(nn.Module):
@@ -245,7 +245,7 @@ class BrainEncoder(nn.Module):
         """True when backward already SUM-all-reduced this module's gradients across ranks (data parallel,
         overlapped with backward); callers then all-reduce only what lives outside the encoder (CLIPLoss.temp)."""
         e = self.engine
-        return e.world > 1 and e.overlap_grad_allreduce
+        return e.group is not None and e.overlap_grad_allreduce
 
     def set_compute_dtype(self, dtype: torch.dtype):
         self.compute_dtype = dtype

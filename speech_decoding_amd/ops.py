@@ -9,14 +9,15 @@ import torch
 
 from . import lib as L
 
-_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
+COMPUTE_DTYPES = tuple(_DT)
 
 
 def dt_code(dtype: torch.dtype) -> int:
     try:
         return _DT[dtype]
     except KeyError:
-        raise L.SdaError(f"unsupported compute dtype {dtype}; use torch.float32 or torch.bfloat16")
+        raise L.SdaError(f"unsupported compute dtype {dtype}; use torch.float32, torch.bfloat16 or torch.float16")
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -79,6 +80,16 @@ UPLOADER = UploadCache()
 def new_rows(B: int, T: int, Cp: int, dtype, device) -> torch.Tensor:
     """Zero-initialised RL buffer: (rows_alloc, Cp)."""
     return torch.zeros((L.rows_alloc(B, T), Cp), dtype=dtype, device=device)
+
+
+def new_rows_uninit(B: int, T: int, Cp: int, dtype, device) -> torch.Tensor:
+    """RL buffer whose VALID rows are left uninitialised (the producing kernel writes all of them); the pad rows in
+    front of every sample and the slack behind the last one are zeroed (two small fills instead of a full memset)."""
+    Tp = L.rows_tp(T)
+    buf = torch.empty((L.rows_alloc(B, T), Cp), dtype=dtype, device=device)
+    buf.as_strided((B, L.ROW_PAD, Cp), (Tp * Cp, Cp, 1), 0).zero_()
+    buf[B * Tp:].zero_()
+    return buf
 
 
 def rows_view(buf: torch.Tensor, B: int, C: int, T: int) -> torch.Tensor:
@@ -302,7 +313,7 @@ def matmul_nt_splitk(xm: torch.Tensor, wm: torch.Tensor, M: int, N: int, K: int,
     """S[i][j] = sum_k xm[i][k] * wm[j][k] (both K-contiguous rows with `pitch`), fp32 (M, pad64(N)) result.
     Runs conv_gemm in split-K mode + ordered slab reduction (loss.py:68)."""
     Np = L.pad_channels(N)
-    slab = 64 if xm.dtype == torch.bfloat16 else 32
+    slab = 32 if xm.dtype == torch.float32 else 64
     nslab = K // slab
     tile_co = 160 if Np % 160 == 0 else (128 if Np % 128 == 0 else 64)
     tiles = ((M + 127) // 128) * (Np // tile_co)

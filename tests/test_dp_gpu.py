@@ -19,20 +19,23 @@ class Args(dict):
     __getattr__ = dict.__getitem__
 
 
-DIMS = dict(C=20, S=3, D1=32, D2=48, F=64, K=4, T=70)
+TOY = dict(C=20, S=3, D1=32, D2=48, F=64, K=4, T=70, B=12)
+# BASELINE configs[2] / configs[3] per-rank shapes (Gwilliams 208 ch x 27 subjects, Brennan 60 ch x 1 subject) at the
+# real layer widths, 8 segments per rank: SyncBN + global negatives + per-group gradient all-reduce at full dims
+REAL_208 = dict(C=208, S=27, D1=270, D2=320, F=1024, K=32, T=360, B=8)
+REAL_60 = dict(C=60, S=1, D1=270, D2=320, F=1024, K=32, T=360, B=8)
 
 
-def build(dtype, P):
+def build(dtype, P, d, dev="cuda:0"):
     from speech_decoding.models import BrainEncoder
     from speech_decoding.utils.loss import CLIPLoss
-    d = DIMS
     loc = O.synthetic_positions(d["C"], seed=1)
     args = Args(num_subjects=d["S"], D1=d["D1"], D2=d["D2"], F=d["F"], K=d["K"], dataset="Gwilliams2022", d_drop=0.1,
                 root_dir=".", preprocs={"last4layers": False}, reduction="mean", init_temperature=3.0,
                 sensor_positions=loc.numpy(), compute_dtype=dtype)
     enc = BrainEncoder(args)
     enc.load_state_dict(P)
-    return enc.to("cuda:0").train(), CLIPLoss(args).to("cuda:0")
+    return enc.to(dev).train(), CLIPLoss(args).to(dev)
 
 
 def grads_of(enc, lossf):
@@ -42,24 +45,31 @@ def grads_of(enc, lossf):
     return out
 
 
-def _worker(rank, world, port, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, ret, d, backend="gloo"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     import datetime
+    # gloo: every rank on cuda:0 (one-GPU box); nccl (= RCCL): one device per rank
+    DEV = f"cuda:{rank}" if backend == "nccl" else "cuda:0"
+    torch.cuda.set_device(DEV)
     # short collective timeout: if one rank fails, the others error out instead of blocking the whole run
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120),
+                                device_id=torch.device(DEV))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         from speech_decoding_amd.distributed import allreduce_gradients, shard_range
-        d = DIMS
         loc = O.synthetic_positions(d["C"], seed=1)
         P = O.seeded_params(d["C"], d["S"], d["D1"], d["D2"], d["F"], d["K"], seed=2, loc=loc)
-        Bg = 12 * world
+        Bg = d["B"] * world
         X, Y, subj = O.synthetic_batch(Bg, d["C"], d["T"], d["F"], d["S"], seed=3)
         lo, hi = shard_range(Bg, rank, world)
-        enc, lossf = build("fp32", P)
+        enc, lossf = build("fp32", P, d, DEV)
         enc.set_drop_centre(4)
-        Yl = Y[lo:hi].to("cuda:0")
+        Yl = Y[lo:hi].to(DEV)
         lossf.prefetch(Yl, torch.float32)                          # async all-gather of Y overlapping the encoder
-        Z = enc(X[lo:hi].to("cuda:0"), subj[lo:hi])
+        Z = enc(X[lo:hi].to(DEV), subj[lo:hi])
         loss = lossf(Yl, Z)
         loss.backward()
         assert enc.grads_are_reduced                                  # encoder grads: all-reduced inside backward
@@ -71,33 +81,48 @@ def _worker(rank, world, port, ret):
         res = dict(loss=float(loss.detach()), Z=Z.detach().float().cpu(), grads=grads_of(enc, lossf), top=top,
                    rm=enc.conv_blocks.conv2.batchnorm1.running_mean.cpu().clone())
         if rank == 0:      # single-process reference on the whole batch, collectives switched off
-            enc1, lossf1 = build("fp32", P)
+            enc1, lossf1 = build("fp32", P, d, DEV)
             enc1.sync_batchnorm = False
             lossf1.global_negatives = False
             enc1.set_drop_centre(4)
-            Z1 = enc1(X.to("cuda:0"), subj)
-            l1 = lossf1(Y.to("cuda:0"), Z1)
+            Z1 = enc1(X.to(DEV), subj)
+            l1 = lossf1(Y.to(DEV), Z1)
             l1.backward()
             local_clf = Classifier(None)
             local_clf.global_candidates = False
             res["ref"] = dict(loss=float(l1.detach()), Z=Z1.detach().float().cpu(), grads=grads_of(enc1, lossf1),
                               rm=enc1.conv_blocks.conv2.batchnorm1.running_mean.cpu().clone(),
-                              top=local_clf(Z1, Y.to("cuda:0")))
+                              top=local_clf(Z1, Y.to(DEV)))
         ret[rank] = res
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_ranks_match_single_process_global_batch(world):
+@pytest.mark.parametrize("world,dims", [(2, TOY), (4, TOY), (2, REAL_208), (2, REAL_60)],
+                         ids=["toy-2", "toy-4", "config3-dims-2", "config4-dims-2"])
+def test_ranks_match_single_process_global_batch(world, dims):
+    _run_ranks(world, dims, "gloo")
+
+
+def test_two_ranks_on_rccl_when_two_gpus_are_visible():
+    """The same check over the real backend: torch.distributed "nccl" = RCCL over xGMI, one device per rank.  Needs two
+    GPUs (the driver's multi-GPU box); on the one-GPU test box the RCCL call sequence is covered at world size 1 by
+    tests/test_rccl_gpu.py."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_ranks(2, TOY, "nccl")
+    _run_ranks(2, REAL_208, "nccl")
+
+
+def _run_ranks(world, dims, backend):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 29700 + (os.getpid() % 1000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    port = 29700 + (os.getpid() % 1000) + world + (dims["C"] % 7) * 10
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, dims, backend)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(180)
+        p.join(300)
     for p in procs:
         if p.is_alive():
             p.terminate()
@@ -105,7 +130,7 @@ def test_ranks_match_single_process_global_batch(world):
     assert [p.exitcode for p in procs] == [0] * world
     out = dict(ret)
     ref = out[0]["ref"]
-    B = 12
+    B = dims["B"]
     for r in range(world):
         assert abs(out[r]["loss"] - ref["loss"]) < 2e-5                       # every rank reports the global loss
         np.testing.assert_allclose(out[r]["Z"].numpy(), ref["Z"][r * B:(r + 1) * B].numpy(), rtol=2e-4, atol=2e-5)

@@ -1,0 +1,94 @@
+"""Parity at the size the bench measures: BASELINE.json configs[1] — 208 sensors x 360 samples, 27 subjects,
+F = 1024, batch 256 — where the launch geometry (sample segments of the weight gradients, XCD-ordered grids, paired
+tiles, workspace sizes) differs from the small fixtures.
+
+  * fp32 training step at B = 256 against the LIVE oracle on this box's host cores (one oracle step: tens of seconds):
+    embeddings, loss, every gradient, BatchNorm running statistics — the 1e-4 gate of north_star;
+  * eval-mode forward at B = 256 in every compute dtype, checked on a random 8-sample subset (eval mode is
+    per-sample independent, so the oracle runs at B = 8)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import brain_oracle as O                                  # noqa: E402
+from tests.parity import operands_as_device_sees_them, rel_l2, round_to   # noqa: E402
+from tests.test_e2e_gpu import DTYPES16, build, grads_by_state_key, make_args, null_grad   # noqa: E402
+
+DEV = "cuda:0"
+C, S, D1, D2, F, K, T, B = 208, 27, 270, 320, 1024, 32, 360, 256
+
+
+def _setup(dtype):
+    loc = O.synthetic_positions(C, seed=0)
+    P = O.seeded_params(C, S, D1, D2, F, K, seed=0, loc=loc)
+    args = make_args(C, S, D1, D2, 512, K, True, loc.numpy(), dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc, lossf, clf = build(args, P, [5.1])
+    X, Y, subj = O.synthetic_batch(B, C, T, F, S, seed=4321)
+    return loc, P, enc, lossf, clf, X, Y, subj
+
+
+def test_config2_full_batch_fp32_train_step_vs_live_oracle():
+    loc, P, enc, lossf, clf, X, Y, subj = _setup("fp32")
+    enc.train()
+    enc.set_drop_centre(5)
+    Yd = Y.to(DEV)
+    Z = enc(X.to(DEV), subj)
+    logits, loss = lossf(Yd, Z, return_logits=True)
+    top1, top10 = clf(Z, Yd)
+    loss.backward()
+    stats = {k: v.clone() for k, v in P.items() if "running" in k or "num_batches" in k}
+    lo, Zo, logits_o, go = O.train_step(P, torch.tensor([5.1]), X, Y, subj, loc=loc, drop_centre=5, stats=stats)
+    Zc = Z.detach().cpu()
+    assert float((Zc - Zo).abs().max()) <= 1e-4 * float(Zo.abs().max()), "embeddings"
+    assert rel_l2(Zc, Zo) < 2e-5
+    assert abs(float(loss.detach()) - float(lo)) < 1e-4
+    np.testing.assert_allclose(logits.cpu().numpy(), logits_o.numpy(), rtol=1e-3, atol=5e-3)
+    assert (top1, top10) == pytest.approx(O.topk_accuracy(Zo, Y))
+    for k, g in grads_by_state_key(enc).items():
+        ref = go[k]
+        if ref is None:                                      # a subject absent from the batch
+            assert g is None or float(g.abs().max()) == 0.0, k
+            continue
+        gf = (torch.view_as_real(g) if g.is_complex() else g).float().cpu().reshape(-1)
+        rf = (torch.view_as_real(ref) if ref.is_complex() else ref).reshape(-1)
+        if null_grad(k):                                     # mathematically zero (feeds a training-mode BatchNorm)
+            assert float(gf.abs().max()) < 1e-4, k
+            continue
+        assert float((gf - rf).abs().max()) <= 2e-3 * float(rf.abs().max()) + 1e-9, (k, float((gf - rf).abs().max()), float(rf.abs().max()))
+        assert rel_l2(gf, rf) < 1e-3, (k, rel_l2(gf, rf))
+    assert abs(float(lossf.temp.grad) - float(go["temp"])) < 1e-3 * max(1.0, abs(float(go["temp"])))
+    sd = enc.state_dict()
+    for k, v in stats.items():
+        if "running" in k:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("dtype", ["fp32"] + DTYPES16)
+def test_config2_full_batch_eval_forward_sampled_against_oracle(dtype):
+    loc, P, enc, lossf, clf, X, Y, subj = _setup(dtype)
+    enc.eval()
+    with torch.no_grad():
+        Z = enc(X.to(DEV), subj)
+        Z_again = enc(X.to(DEV), subj)
+    assert Z.data_ptr() != Z_again.data_ptr()                 # a fresh tensor per forward, as in the reference
+    assert torch.equal(Z, Z_again)                            # bitwise run-to-run reproducible
+    pick = torch.from_numpy(np.random.RandomState(3).choice(B, 8, replace=False)).sort().values
+    Pr = operands_as_device_sees_them(P, dtype)
+    Zo = O.brain_encoder_forward(Pr, round_to(X[pick], dtype), subj[pick], training=False)
+    got = Z[pick.to(DEV)].float().cpu()
+    if dtype == "fp32":
+        assert float((got - Zo).abs().max()) <= 1e-4 * float(Zo.abs().max())
+    else:
+        assert rel_l2(got, Zo) < REL_EVAL[dtype], rel_l2(got, Zo)
+        assert float((got - Zo).abs().max()) <= MAX_EVAL[dtype] * float(Zo.abs().max())
+
+
+# 16-bit storage between the ~20 kernels of a forward: calibrated on tests/precision_survey.py (x ~2 margin)
+REL_EVAL = {"bf16": 1.5e-2, "fp16": 2.5e-3}
+MAX_EVAL = {"bf16": 6e-2, "fp16": 1e-2}

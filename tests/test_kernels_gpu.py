@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 from oracle import brain_oracle as O   # noqa: E402
 
 DEV = "cuda:0"
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 @pytest.fixture(scope="module")
@@ -28,6 +28,8 @@ def ops():
 def tol(dtype, k_terms=1):
     if dtype == torch.float32:
         return dict(rtol=2e-5, atol=2e-5)
+    if dtype == torch.float16:         # 2^-11 per stored value (bf16: 2^-8)
+        return dict(rtol=2.5e-3, atol=2.5e-3 * math.sqrt(max(1, k_terms)) / 8)
     return dict(rtol=2e-2, atol=2e-2 * math.sqrt(max(1, k_terms)) / 8)
 
 

@@ -23,7 +23,7 @@ def tiny_args(dataset):
     return args, loc
 
 
-def oracle_loop(args, loc, init_state, data_cpu):
+def oracle_loop(args, loc, init_state, data_cpu, updates=2):
     """train.py:166-233 restated on the oracle (CPU, fp32)."""
     names = [k for k, v in init_state.items() if (v.is_floating_point() or v.is_complex()) and "running" not in k
              and not k.endswith((".cos", ".sin"))]
@@ -36,7 +36,7 @@ def oracle_loop(args, loc, init_state, data_cpu):
     for epoch in range(int(args.epochs)):
         tl, t10 = [], []
         loss = None
-        for X, Y, subj in data_cpu.train_batches(int(args.batch_size), 2):
+        for X, Y, subj in data_cpu.train_batches(int(args.batch_size), updates):
             Q = dict(P)
             Q.update(dict(zip(names, params)))
             centre = int(np.random.randint(loc.shape[0]))
@@ -92,3 +92,46 @@ def test_training_driver_matches_oracle_loop(dataset, tmp_path, monkeypatch):
         assert float((got - ref).abs().max()) < 2.5 * float(args.lr) * (6 if dataset == "Gwilliams2022" else 3) + 1e-6, k
         moved += float((got - init[k] if not init[k].is_complex() else torch.view_as_real(saved[k]) - torch.view_as_real(init[k])).abs().max())
     assert moved > 0
+
+
+# 200 optimiser steps (20 epochs x 10 updates) of the 16-bit HIP paths against the fp32 oracle loop on the same seeded
+# synthetic dataset, same initial weights, same dropout centres.  Training is chaotic in the last bits, so the curves
+# are held to a band, not to equality: per-epoch mean training loss within LOSS_BAND (relative, plus a small absolute
+# floor of 0.5 in the denominator: the training loss ends near 0.02), test loss within TEST_BAND, top-10 test accuracy within ACC_BAND, and the same overall descent.
+LOSS_BAND = {"bf16": 0.10, "fp16": 0.05}
+TEST_BAND = {"bf16": 0.10, "fp16": 0.05}
+ACC_BAND = {"bf16": 0.15, "fp16": 0.10}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_200_step_training_curve_of_16bit_paths_tracks_the_fp32_oracle(dtype, tmp_path, monkeypatch):
+    import train as T
+    from speech_decoding.models import BrainEncoder
+    from speech_decoding_amd import load_config
+    monkeypatch.chdir(tmp_path)
+    loc = O.synthetic_positions(20, seed=7)
+    args = load_config(overrides=["dataset=Gwilliams2022", "num_subjects=4", "D1=32", "D2=48", "F=64", "K=4", "batch_size=16",
+                                  "epochs=20", "num_channels=20", "preprocs.last4layers=False", "preprocs.seq_len_sec=1",
+                                  "preprocs.brain_resample_rate=64", "preprocs.baseline_len_sec=0.25", "lr=3e-4",
+                                  "synthetic_segments=200", "updates_per_epoch=10", "split_ratio=0.8", f"compute_dtype={dtype}"])
+    args["sensor_positions"] = loc.numpy()
+    torch.manual_seed(0)
+    init = {k: v.clone() for k, v in BrainEncoder(args).state_dict().items()}
+    data_cpu = T.SyntheticSegments(args, 200, "cpu", seed=1234)
+    np.random.seed(0)
+    want, _ = oracle_loop(args, loc, init, data_cpu, updates=10)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    hist, enc, lossf = T.run(args, log=lambda *a: None)
+    assert len(hist) == len(want) == 20
+    dev = {"train": 0.0, "test": 0.0, "acc": 0.0}
+    for got, ref in zip(hist, want):
+        dev["train"] = max(dev["train"], abs(got["train_loss"] - ref["train_loss"]) / (ref["train_loss"] + 0.5))
+        dev["test"] = max(dev["test"], abs(got["test_loss"] - ref["test_loss"]) / (ref["test_loss"] + 0.5))
+        dev["acc"] = max(dev["acc"], abs(got["testTop10acc"] - ref["testTop10acc"]))
+    msg = f"{dtype}: max deviations {dev}; final train loss {hist[-1]['train_loss']:.4f} vs {want[-1]['train_loss']:.4f}"
+    assert dev["train"] <= LOSS_BAND[dtype] and dev["test"] <= TEST_BAND[dtype] and dev["acc"] <= ACC_BAND[dtype], msg
+    # the run learns: the loss fell by a comparable factor in both
+    drop_got, drop_ref = hist[-1]["train_loss"] / hist[0]["train_loss"], want[-1]["train_loss"] / want[0]["train_loss"]
+    assert drop_ref < 0.9 and abs(drop_got - drop_ref) < 0.1, (drop_got, drop_ref, msg)
+    assert abs(hist[-1]["temp"] - want[-1]["temp"]) < 2e-2

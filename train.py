@@ -106,9 +106,13 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
         wandb.init(project=args.wandb.project, entity=args.wandb.entity, config=dict(args), save_code=True)
         wandb.run.name = args.wandb.run_name + "_" + str(args.split_mode)
 
+    from speech_decoding_amd.amp import LossScaler
+    scaler = LossScaler.for_dtype(brain_encoder.compute_dtype, float(args.get("fp16_loss_scale", 1024.0)))   # no-op unless fp16
+
     def backward_and_step(loss):
         optimizer.zero_grad()
-        loss.backward()
+        scaler.scale(loss).backward()
+        scaler.unscale_(params)
         if world > 1:
             allreduce_gradients(list(loss_func.parameters()) if brain_encoder.grads_are_reduced else params)
         optimizer.step()
