@@ -21,9 +21,9 @@ class Args(dict):
 
 TOY = dict(C=20, S=3, D1=32, D2=48, F=64, K=4, T=70, B=12)
 # BASELINE configs[2] / configs[3] per-rank shapes (Gwilliams 208 ch x 27 subjects, Brennan 60 ch x 1 subject) at the
-# real layer widths, 8 segments per rank: SyncBN + global negatives + per-group gradient all-reduce at full dims
-REAL_208 = dict(C=208, S=27, D1=270, D2=320, F=1024, K=32, T=360, B=8)
-REAL_60 = dict(C=60, S=1, D1=270, D2=320, F=1024, K=32, T=360, B=8)
+# real layer widths, 12 segments per rank (the Classifier needs 10 candidates): SyncBN + global negatives + per-group gradient all-reduce at full dims
+REAL_208 = dict(C=208, S=27, D1=270, D2=320, F=1024, K=32, T=360, B=12)
+REAL_60 = dict(C=60, S=1, D1=270, D2=320, F=1024, K=32, T=360, B=12)
 
 
 def build(dtype, P, d, dev="cuda:0"):

@@ -90,5 +90,5 @@ def test_config2_full_batch_eval_forward_sampled_against_oracle(dtype):
 
 
 # 16-bit storage between the ~20 kernels of a forward: calibrated on tests/precision_survey.py (x ~2 margin)
-REL_EVAL = {"bf16": 1.5e-2, "fp16": 2.5e-3}
-MAX_EVAL = {"bf16": 6e-2, "fp16": 1e-2}
+REL_EVAL = {"bf16": 4e-2, "fp16": 5e-3}
+MAX_EVAL = {"bf16": 8e-2, "fp16": 1e-2}

@@ -97,10 +97,14 @@ def test_training_driver_matches_oracle_loop(dataset, tmp_path, monkeypatch):
 # 200 optimiser steps (20 epochs x 10 updates) of the 16-bit HIP paths against the fp32 oracle loop on the same seeded
 # synthetic dataset, same initial weights, same dropout centres.  Training is chaotic in the last bits, so the curves
 # are held to a band, not to equality: per-epoch mean training loss within LOSS_BAND (relative, plus a small absolute
-# floor of 0.5 in the denominator: the training loss ends near 0.02), test loss within TEST_BAND, top-10 test accuracy within ACC_BAND, and the same overall descent.
-LOSS_BAND = {"bf16": 0.10, "fp16": 0.05}
-TEST_BAND = {"bf16": 0.10, "fp16": 0.05}
-ACC_BAND = {"bf16": 0.15, "fp16": 0.10}
+# floor of 0.5 in the denominator: the training loss ends near 0.02), test loss within TEST_BAND, top-10 test accuracy
+# within the two ACC bands, and the same overall descent.
+LOSS_BAND = {"bf16": 0.05, "fp16": 0.02}         # measured 0.005 (bf16)
+TEST_BAND = {"bf16": 0.05, "fp16": 0.02}         # measured 0.005 (bf16)
+# top-10 accuracy over the 40 test segments moves in steps of 0.025 and, while the positives hover around rank 10 in the
+# first epochs, by many steps for a 1 % change of the logits: bound the mean deviation tightly, single epochs loosely
+ACC_MEAN_BAND = {"bf16": 0.08, "fp16": 0.05}
+ACC_MAX_BAND = {"bf16": 0.30, "fp16": 0.15}
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
@@ -125,12 +129,16 @@ def test_200_step_training_curve_of_16bit_paths_tracks_the_fp32_oracle(dtype, tm
     hist, enc, lossf = T.run(args, log=lambda *a: None)
     assert len(hist) == len(want) == 20
     dev = {"train": 0.0, "test": 0.0, "acc": 0.0}
+    acc_dev = [abs(got["testTop10acc"] - ref["testTop10acc"]) for got, ref in zip(hist, want)]
     for got, ref in zip(hist, want):
         dev["train"] = max(dev["train"], abs(got["train_loss"] - ref["train_loss"]) / (ref["train_loss"] + 0.5))
         dev["test"] = max(dev["test"], abs(got["test_loss"] - ref["test_loss"]) / (ref["test_loss"] + 0.5))
         dev["acc"] = max(dev["acc"], abs(got["testTop10acc"] - ref["testTop10acc"]))
-    msg = f"{dtype}: max deviations {dev}; final train loss {hist[-1]['train_loss']:.4f} vs {want[-1]['train_loss']:.4f}"
-    assert dev["train"] <= LOSS_BAND[dtype] and dev["test"] <= TEST_BAND[dtype] and dev["acc"] <= ACC_BAND[dtype], msg
+    msg = (f"{dtype}: max deviations {dev}; mean acc deviation {np.mean(acc_dev):.3f}; final train loss {hist[-1]['train_loss']:.4f} "
+           f"vs {want[-1]['train_loss']:.4f}; test top-10 by epoch {[round(float(h['testTop10acc']), 3) for h in hist]} vs "
+           f"{[round(float(w['testTop10acc']), 3) for w in want]}")
+    assert dev["train"] <= LOSS_BAND[dtype] and dev["test"] <= TEST_BAND[dtype], msg
+    assert np.mean(acc_dev) <= ACC_MEAN_BAND[dtype] and dev["acc"] <= ACC_MAX_BAND[dtype], msg
     # the run learns: the loss fell by a comparable factor in both
     drop_got, drop_ref = hist[-1]["train_loss"] / hist[0]["train_loss"], want[-1]["train_loss"] / want[0]["train_loss"]
     assert drop_ref < 0.9 and abs(drop_got - drop_ref) < 0.1, (drop_got, drop_ref, msg)
