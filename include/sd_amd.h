@@ -38,9 +38,10 @@ enum { SDA_F32 = 0, SDA_BF16 = 1, SDA_F16 = 2 };   /* storage + MFMA operand typ
 enum { SDA_EPI_GELU = 1,
        SDA_CONV_SINGLE_TILE = 4096, /* force one 128-row tile per workgroup */
        SDA_CONV_PAIR_TILES = 8192,  /* two tiles per workgroup sharing one weight slab (default: one) */
-       SDA_CONV_PERSIST = 16384     /* kernel size 3, 160-channel tiles: persistent workgroups with the epilogue of
-                                       tile i issued inside the K loop of tile i+1 (conv3_persist.hip); silently
-                                       falls back to the tile-per-workgroup kernel for shapes it does not cover */ };
+       SDA_CONV_ONE_PER_CU = 32768, /* with SDA_CONV_FLAT_TILES: at most one workgroup per CU (half the LDS stays free) */
+       SDA_CONV_FLAT_TILES = 16384  /* kernel size 3 with Cout_p % 160 == 0: 256-row x 160-channel tiles cut from the
+                                       flat row space, two workgroups per CU (conv3_flat.hip); other shapes ignore the
+                                       flag.  `stats` then has sda_conv_stats_rows(...) rows instead of B * n_t_tiles */ };
 
 int sda_abi_version(void);
 const char* sda_last_error(void);
@@ -133,6 +134,8 @@ typedef struct sda_conv_args {
 } sda_conv_args;
 int sda_conv_gemm(const sda_conv_args* a, void* stream);
 int sda_conv_n_t_tiles(int T);
+/* number of [2][Cout_p] rows of `stats` a launch with these parameters writes */
+int sda_conv_stats_rows(int B, int T, int KS, int Cout_p, int flags);
 
 /* BatchNorm1d (training statistics) over valid rows.
  * finalize: per-tile partial (sum, sumsq) -> mean/rstd, fused affine scale/shift, running-stat update

@@ -456,7 +456,11 @@ static int dispatch_conv_nt(const sda_conv_args& a, hipStream_t st) {
 
 template <typename E>
 static int dispatch_conv(const sda_conv_args& a, hipStream_t st) {
-  if ((a.flags & SDA_CONV_PERSIST) && conv3_persist_supports(a)) return launch_conv3_persist(a, st);
+  if ((a.flags & SDA_CONV_FLAT_TILES) && a.KS == 3 && a.Cout_p % 160 == 0) {
+    // (exactly the condition sda_conv_stats_rows uses: the statistics rows a caller sized must be the rows written)
+    if (!conv3_flat_supports(a)) { set_error("conv_gemm: SDA_CONV_FLAT_TILES needs a plain row-layout kernel-3 convolution"); return -1; }
+    return launch_conv3_flat(a, st);
+  }
   if (a.Cout_p % 160 == 0) return dispatch_conv_nt<E, 160>(a, st);
   if (a.Cout_p % 128 == 0) return dispatch_conv_nt<E, 128>(a, st);
   return dispatch_conv_nt<E, 64>(a, st);

@@ -1,4 +1,4 @@
-// LDS tile geometry shared by the conv kernels (conv_gemm.hip, conv3_persist.hip).
+// LDS tile geometry shared by the conv kernels (conv_gemm.hip, conv3_flat.hip).
 #pragma once
 #include "sd_common.h"
 
@@ -17,8 +17,9 @@ constexpr int XS_BYTES = XROWS * ROW_B;            // 10 KB
 __device__ inline int sw64(int row) { return (row >> 1) & 2; }
 __device__ inline int lds_sw64(int row, int chunk) { return row * ROW_B + ((chunk ^ sw64(row)) << 4); }
 
-// conv3_persist.hip
-int launch_conv3_persist(const sda_conv_args& a, hipStream_t st);
-bool conv3_persist_supports(const sda_conv_args& a);
+// conv3_flat.hip
+int launch_conv3_flat(const sda_conv_args& a, hipStream_t st);
+bool conv3_flat_supports(const sda_conv_args& a);
+int conv3_flat_stat_rows(int B, int T);
 
 }  // namespace sda

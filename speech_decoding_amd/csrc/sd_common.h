@@ -237,6 +237,22 @@ __device__ inline void lds_dma16(const void* gsrc, uint32_t lds_dst) {
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
 }
+// The same with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset: when
+// the piece's row is wave-uniform all per-piece arithmetic is scalar and ONE offset register serves every piece.
+// (s_nop 4: a base that was just produced by v_readfirstlane needs 5 wait states before a VMEM instruction reads it.)
+__device__ inline void lds_dma16_sv(const void* sbase_in, uint32_t voff, uint32_t lds_dst) {
+  // the base IS wave-uniform by construction; where hipcc cannot prove it, make it provable (folds away where it can)
+  const uint64_t sb64 = (uint64_t)(uintptr_t)sbase_in;
+  // (the builtin returns int: go through uint32_t, or an address with bit 31 set sign-extends into the high half)
+  const uint32_t sb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sb64 >> 32));
+  const uint32_t sb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sb64);
+  const void* sbase = (const void*)(uintptr_t)(((uint64_t)sb_hi << 32) | (uint64_t)sb_lo);
+  uint32_t keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
 __device__ inline uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const void*)p);
 }

@@ -87,6 +87,12 @@ class EncoderEngine:
         self.pack_on_side_stream = True      # per-step operand packing runs beside the first layers, not in front
         self.forward_pair_tiles = True       # forward k = 3 convs (nothing competes for the CU's LDS there): two
                                              # tiles per workgroup share each weight slab — fewer LDS-DMA bytes per FLOP
+        self.flat_tiles_forward = True       # k = 3 convs on the 256-row flat-tile kernel (conv3_flat.hip) where it applies
+        # backward keeps the 128-row tile kernel (40 KB of LDS per workgroup): the flat kernel's two 76 KB workgroups fill a
+        # CU's LDS, the weight-gradient GEMMs of the side stream then wait for the conv instead of running beside it
+        # (measured in the step: +2 %; with one flat workgroup per CU: +7 %)
+        self.flat_tiles_backward = False
+        self.flat_backward_one_per_cu = False
         self._side = {}
 
     @property
@@ -242,6 +248,8 @@ class EncoderEngine:
             if need_grad:
                 ctx.packed_T = bwd_plan.run(P)
         k3_flags = L.CONV_PAIR_TILES if self.forward_pair_tiles else 0
+        if self.flat_tiles_forward:
+            k3_flags |= L.CONV_FLAT_TILES
 
         # ---- SubjectBlock (models.py:111-117)
         Xt = rows("Xt", d.Cp)
@@ -274,10 +282,10 @@ class EncoderEngine:
                 h = rows(f"b{k}.h{j}", d.D2p)
                 bnp = f"b{k}.bn{j}"
                 if training:
-                    stats = torch.empty((ntile, 2, d.D2p), dtype=torch.float32, device=dev)
+                    nt = ops.conv_stats_rows(B, T, 3, d.D2p, k3_flags)
+                    stats = torch.empty((nt, 2, d.D2p), dtype=torch.float32, device=dev)
                     ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, stats=stats, alg_dims=alg,
                                   flags=k3_flags)
-                    nt = ntile
                     if self.group is not None:   # one 2*Cp-float all-reduce per BatchNorm
                         stats = ops.reduce_slabs(stats).reshape(1, 2, d.D2p)
                         self._allreduce(stats)
@@ -407,12 +415,13 @@ class EncoderEngine:
             """Data-gradient conv.  bn = (h, coef): `out` is the gradient entering GELU(BN(h)); the conv's epilogue
             then also emits the per-tile BatchNorm-backward sums (returned as second value) — the separate
             reduction pass over (out, h) is not needed."""
+            bflags = (L.CONV_FLAT_TILES | (L.CONV_ONE_PER_CU if self.flat_backward_one_per_cu else 0)) if (self.flat_tiles_backward and KS == 3) else 0
             if bn is None or not self.fuse_bn_backward_stats or bn[1] is None:
                 return ops.conv_gemm(dy, ctx.packed_T[key], out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx,
-                                     alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2])), None
-            st = torch.empty((ntile, 2, out.shape[1]), dtype=torch.float32, device=dev)
+                                     alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]), flags=bflags), None
+            st = torch.empty((ops.conv_stats_rows(B, T, KS, out.shape[1], bflags), 2, out.shape[1]), dtype=torch.float32, device=dev)
             ops.conv_gemm(dy, ctx.packed_T[key], out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx, stats=st,
-                          bn_x=bn[0], bn_coef=bn[1], alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]))
+                          bn_x=bn[0], bn_coef=bn[1], alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]), flags=bflags)
             return out, st
 
         def bias_grad(cs, C, glu_half=0, glu_half_p=0):

@@ -15,7 +15,7 @@ F32, BF16, F16 = 0, 1, 2
 ROW_PAD = 16
 CH_ALIGN = 64
 EPI_GELU = 1
-CONV_SINGLE_TILE, CONV_PAIR_TILES, CONV_PERSIST = 4096, 8192, 16384
+CONV_SINGLE_TILE, CONV_PAIR_TILES, CONV_FLAT_TILES, CONV_ONE_PER_CU = 4096, 8192, 16384, 32768
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "sda_unpack_vector": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sda_conv_gemm": (i32, [C.POINTER(ConvArgs), vp]),
     "sda_conv_n_t_tiles": (i32, [i32]),
+    "sda_conv_stats_rows": (i32, [i32, i32, i32, i32, i32]),
     "sda_bn_finalize": (i32, [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "sda_reduce_stats": (i32, [vp, i32, vp, vp, i32, vp]),
     "sda_bn_gelu_backward_from_stats": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, f64, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

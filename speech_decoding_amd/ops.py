@@ -309,6 +309,11 @@ def n_t_tiles(T: int) -> int:
     return (T + 127) // 128
 
 
+def conv_stats_rows(B: int, T: int, KS: int, Cout_p: int, flags: int = 0) -> int:
+    """Rows of the per-tile statistics buffer a conv_gemm launch with these parameters writes."""
+    return L.load().sda_conv_stats_rows(B, T, KS, Cout_p, flags)
+
+
 def matmul_nt_splitk(xm: torch.Tensor, wm: torch.Tensor, M: int, N: int, K: int, pitch: int) -> torch.Tensor:
     """S[i][j] = sum_k xm[i][k] * wm[j][k] (both K-contiguous rows with `pitch`), fp32 (M, pad64(N)) result.
     Runs conv_gemm in split-K mode + ordered slab reduction (loss.py:68)."""

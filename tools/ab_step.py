@@ -1,0 +1,58 @@
+"""A/B of engine switches on the config-2 training step in ONE process, interleaved rounds (box-to-box and run-to-run
+variance is larger than most of the effects being compared).  Usage: python tools/ab_step.py [rounds]"""
+import itertools, os, sys, time, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from speech_decoding_amd import BrainEncoder, CLIPLoss, load_config
+from speech_decoding_amd.layout import synthetic_positions
+from speech_decoding_amd import loss as sda_loss
+from speech_decoding_amd.optim import FusedAdam
+
+C, S, T, F, B = 208, 27, 360, 1024, 256
+dev = torch.device("cuda", 0)
+torch.manual_seed(0); np.random.seed(0)
+cfg = load_config(overrides=[f"num_subjects={S}", "compute_dtype=bf16", "dataset=Gwilliams2022"])
+cfg["sensor_positions"] = synthetic_positions(C, seed=0).numpy()
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    enc = BrainEncoder(cfg).to(dev).train()
+lossf = CLIPLoss(cfg).to(dev).train()
+params = list(enc.parameters()) + list(lossf.parameters())
+opt = FusedAdam(params, lr=3e-4)
+g = torch.Generator(device=dev).manual_seed(1)
+X = torch.randn(B, C, T, generator=g, device=dev)
+Y = torch.randn(B, F, T, generator=g, device=dev)
+rng = np.random.RandomState(0)
+
+def step():
+    subj = torch.from_numpy(rng.randint(0, S, size=B).astype(np.int32))
+    lossf.prefetch(Y, enc.compute_dtype)
+    Z = enc(X, subj)
+    loss = lossf(Y, Z)
+    sda_loss.retrieval_ranks(Y, Z)
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+
+def timed(n=10):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): step()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+
+variants = {}
+for name in sys.argv[2:] or ["base", "flat_fwd", "flat_both", "flat_both_1cu"]:
+    variants[name] = dict(base=(False, False, False), flat_fwd=(True, False, False), flat_bwd=(False, True, False), flat_both=(True, True, False),
+                          flat_both_1cu=(True, True, True), flat_bwd_1cu=(False, True, True))[name]
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+eng = enc.engine
+res = {k: [] for k in variants}
+for k, (f, b, o) in variants.items():           # warm-up of every variant (workspaces, attribute calls)
+    eng.flat_tiles_forward, eng.flat_tiles_backward, eng.flat_backward_one_per_cu = f, b, o
+    for _ in range(3): step()
+for r in range(rounds):
+    for k, (f, b, o) in variants.items():
+        eng.flat_tiles_forward, eng.flat_tiles_backward, eng.flat_backward_one_per_cu = f, b, o
+        res[k].append(timed())
+for k, v in res.items():
+    print(f"{k:10s} median {np.median(v):.3f} ms  min {min(v):.3f}  all {[round(x, 3) for x in v]}")

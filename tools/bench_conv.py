@@ -16,8 +16,8 @@ def timeit(fn, n=20, warm=3):
 def main():
     dev = "cuda:0"
     B, T = 256, 360
-    for dtype in (torch.bfloat16, torch.float32):
-        for (cin, cout, KS, dil) in [(320, 320, 3, 4), (320, 640, 3, 2), (320, 320, 1, 0), (640, 1024, 1, 0)]:
+    for dtype in (torch.bfloat16,):
+        for (cin, cout, KS, dil) in [(320, 320, 3, 4), (320, 640, 3, 2)]:
             x = ops.new_rows(B, T, cin, dtype, dev); x.normal_()
             w = torch.randn(cout, cin, KS, device=dev) / math.sqrt(KS * cin)
             wp = ops.pack_conv_weight(w, cout, cin, dtype)
@@ -29,11 +29,18 @@ def main():
             for name, kw in [("full", dict(bias=bias, res=res, stats=stats)), ("plain", dict()),
                              ("no_epi", dict(flags=256)), ("no_main", dict(bias=bias, res=res, stats=stats, flags=512)),
                              ("neither", dict(flags=768)), ("pair_full", dict(bias=bias, res=res, stats=stats, flags=8192)),
-                             ("persist", dict(bias=bias, res=res, stats=stats, flags=16384)), ("persist_plain", dict(flags=16384)),
-                             ("persist_bias", dict(bias=bias, flags=16384)), ("persist_res", dict(res=res, flags=16384)),
-                             ("persist_stats", dict(stats=stats, flags=16384)), ("persist_nostore", dict(flags=16384 | 256))]:
+                             ("flat", dict(bias=bias, res=res, stats=stats, flags=16384)), ("flat_plain", dict(flags=16384)),
+                             ("flat_noepi", dict(flags=16384 | 256)),
+                             ("flat_nostag", dict(bias=bias, res=res, stats=stats, flags=16384 | 1024)),
+                             ("flat_nostag_noepi", dict(flags=16384 | 1024 | 256)),
+                             ("flat_rounds", dict(bias=bias, res=res, stats=stats, flags=16384 | 2048 | 1024)),
+                             ("flat_rounds_noepi", dict(flags=16384 | 2048 | 1024 | 256)),
+                             ("flat_nostag_noprio", dict(bias=bias, res=res, stats=stats, flags=16384 | 1024 | 64)),
+                             ("flat_nostag_noepi_noprio", dict(flags=16384 | 1024 | 256 | 64))]:
+                if KS != 3 and name.startswith("flat"):
+                    continue
                 us = timeit(lambda: ops.conv_gemm(x, wp, y, B=B, T=T, KS=KS, dil=dil, **kw))
-                print(f"conv {str(dtype)[6:]:8s} {cin}->{cout} k{KS} {name:8s} {us:8.1f} us  {fl/us/1e6:7.1f} TF", flush=True)
+                print(f"conv {str(dtype)[6:]:8s} {cin}->{cout} k{KS} {name:28s} {us:8.1f} us  {fl/us/1e6:7.1f} TF", flush=True)
             if KS == 3 or cout == 1024:
                 dy = ops.new_rows(B, T, cout, dtype, dev); dy.normal_()
                 tile_m = 160 if cout % 160 == 0 else 128

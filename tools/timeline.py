@@ -1,20 +1,40 @@
-"""Print one training step's kernel timeline from a rocprofv3 --kernel-trace CSV (diagnostic)."""
-import csv, sys, collections
+"""Stream-level view of one training step from a rocprofv3 --kernel-trace CSV (diagnostic):
+busy time per HIP stream, time with no / one / several kernels in flight, the largest gaps of the main stream, and per
+kernel family the time it spends alone vs beside a kernel of another stream.
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tr -- python3 bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-kernel-timer --no-host-sync-leg
+    python tools/timeline.py gpurun_out/tr/*/*_kernel_trace.csv"""
+import collections, csv, re, sys
+import numpy as np
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# find step boundaries: the pack_rows kernel of X starts a step (first kernel of forward)
-idx = [i for i, r in enumerate(rows) if "sa_fwd_partial" in r["Kernel_Name"]]
-step = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) - 3
-lo, hi = idx[step], idx[step + 1]
-t0 = int(rows[lo]["Start_Timestamp"])
-prev_end = {}
-tot = collections.defaultdict(float)
-for r in rows[lo:hi]:
-    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-    q = r.get("Queue_Id", "?")
-    name = r["Kernel_Name"].replace("void sda::", "").replace("sda::", "")[:60]
-    gap = s - prev_end.get(q, s)
-    prev_end[q] = e
-    tot[name] += (e - s) / 1e3
-    print(f"{s/1e3:9.1f} {(e-s)/1e3:8.1f} gap {gap/1e3:7.1f} q{q} {name}")
-print("step span us:", (int(rows[hi]["Start_Timestamp"]) - t0) / 1e3)
+ad = [i for i, r in enumerate(rows) if "adam_multi" in r["Kernel_Name"]]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else -3
+lo, hi = ad[k - 1] + 1, ad[k] + 1
+t0, t1 = int(rows[lo]["Start_Timestamp"]), int(rows[hi - 1]["End_Timestamp"])
+print(f"step span {(t1 - t0) / 1e3:.1f} us, {hi - lo} kernels")
+def short(n):
+    n = n.replace("void sda::", "").replace("sda::", "")
+    m = re.match(r"([a-z_0-9A-Z]+)<([^>]*)>", n)
+    return (m.group(1) + "<" + m.group(2).replace("unsigned short", "bf16").replace(" ", "") + ">") if m else n.split("(")[0][:40]
+ks = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, r["Stream_Id"], short(r["Kernel_Name"])) for r in rows[lo:hi]]
+bys = collections.defaultdict(list)
+for s, e, q, n in ks: bys[q].append((s, e, n))
+for q, v in sorted(bys.items(), key=lambda kv: -len(kv[1])):
+    print(f"stream {q}: {len(v)} kernels, busy {sum(e - s for s, e, _ in v) / 1e3:.0f} us, active {v[0][0] / 1e3:.0f}..{v[-1][1] / 1e3:.0f}")
+ev = sorted([(s, 1) for s, e, q, n in ks] + [(e, -1) for s, e, q, n in ks])
+cur = last = 0; hist = collections.Counter()
+for t, d in ev:
+    hist[min(cur, 2)] += t - last; cur += d; last = t
+print("no kernel in flight %.0f us, exactly one %.0f us, two or more %.0f us" % tuple(hist[i] / 1e3 for i in range(3)))
+main = max(bys.values(), key=len)
+gaps = sorted([((main[i + 1][0] - main[i][1]) / 1e3, main[i][2], main[i + 1][2]) for i in range(len(main) - 1)], reverse=True)
+print("main stream: gaps sum %.0f us; largest:" % sum(g for g, _, _ in gaps if g > 0))
+for g, a, b in gaps[:8]: print(f"   {g:7.1f} us  {a} -> {b}")
+# alone vs overlapped time per family
+fam = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for s, e, q, n in ks:
+    ov = sum(max(0, min(e, e2) - max(s, s2)) for s2, e2, q2, _ in ks if q2 != q and s2 < e and e2 > s)
+    f = fam[n]; f[0] += 1; f[1] += (e - s) / 1e3; f[2] += min(ov, e - s) / 1e3
+print("family: launches, total us, of which beside another stream's kernel")
+for n, (c, tot, ov) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:22]:
+    print(f"   {n:46s} {c:3d} {tot:8.0f} {ov:8.0f}")
