@@ -110,9 +110,12 @@ struct FTileCtx {            // per-workgroup constants shared by all its tiles
 // the epilogue leaves free, issued one barrier ahead of its use — no registers (the accumulators of the later slices are
 // live and a spilled register's reload waits for every store in flight), 1 KB per request instead of 16 B per lane.
 // fp32 (a slice would be 40 KB): per-thread 16-byte loads, one row ahead.
-template <typename E, bool BN, int MREP, bool RESX>
+// STAMP (diagnostic build, never the product path): s_memtime stamps split every tap phase of the K loop into
+// [barrier exit -> operands in registers] [MFMA + DMA issue] [vmcnt wait] [barrier]; the four cycle sums of wave 0 go to
+// st[0..3] (+ the phase count in st[4]).  Shares are meaningful, the run time of this build is not.
+template <typename E, bool BN, int MREP, bool RESX, bool STAMP = false>
 __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char* smem, const FTileCtx& c, const long f0,
-                                          const int stat_row) {
+                                          const int stat_row, unsigned long long* st = nullptr) {
   constexpr int SLAB = ROW_B / (int)sizeof(E);
   constexpr int PER16 = Elem<E>::PER16;
   constexpr int CH = Vec16<E>::N;
@@ -165,8 +168,16 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
 
   const int nslab = c.nslab;
   static_for<0, S::NP>([&](auto ic) { issue(0, ic); });      // K-step 0 whole; later steps group by group
+  unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, sAB = 0, sBC = 0, sCD = 0, sDA = 0, nph = 0;
+  auto now = [&]() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  };
   for (int s = 0; s < nslab; ++s) {
-    const bool more = s + 1 < nslab;
+    const bool more = s + 1 < nslab && !(a.flags & 16);      // flag 16 (diagnostic): no DMA inside the K loop (results are garbage)
     const unsigned char* xs = smem + (s & 1) * F_XB;
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap) {
@@ -178,7 +189,9 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      if constexpr (STAMP) { tD = now(); if (nph) sCD += tD - tC; }
       __builtin_amdgcn_s_barrier();                          // ... for every wave; the slots written below are consumed
+      if constexpr (STAMP) { tA = now(); if (nph) sDA += tA - tD; }
       const unsigned char* ws = smem + 2 * F_XB + ((3 * s + tap) & 3) * F_WB;
       uint4 bf[F_NREP];
       const int wrow = wave_n * (F_CO / 2) + lr;
@@ -190,6 +203,7 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
       // before the current one's MFMAs: hipcc will not move an LDS read across the asm statements.
       constexpr int every = MREP / 4;
       uint4 af = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow, lq));
+      if constexpr (STAMP) { tB = now(); sAB += tB - tA; }
       static_for<0, MREP>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         uint4 af_next = af;
@@ -206,7 +220,11 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
         }
         af = af_next;
       });
+      if constexpr (STAMP) { tC = now(); sBC += tC - tB; ++nph; }
     }
+  }
+  if constexpr (STAMP) {
+    if (st && c.tid == 0) { st[0] += sAB; st[1] += sBC; st[2] += sCD; st[3] += sDA; st[4] += nph; }
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -381,7 +399,7 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
   __syncthreads();            // the next tile's LDS-DMA overwrites the staging / reduction area
 }
 
-template <typename E, bool BN, bool RESX>
+template <typename E, bool BN, bool RESX, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void conv3_flat_kernel(const sda_conv_args a, const int n_units, const int units_per_wg,
                                                             const int runs_per_co, const long total_rows, const int Tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv3_flat_kernel(const sda_conv_args 
   else { pairs = n >> 1; lead = 0; tail = 0; }
   // diagnostic (flag 32, `partial` = a buffer of 16 x 8 bytes per workgroup that nothing else reads): wall-clock stamps
   // (100 MHz) at the start and after every tile, plus where the workgroup ran — the timeline behind DESIGN.md's numbers
-  unsigned long long* dbg = (a.flags & 32) && a.partial ? reinterpret_cast<unsigned long long*>(a.partial) + (size_t)blockIdx.x * 16 : nullptr;
+  unsigned long long* dbg = (a.flags & 32) && a.partial ? reinterpret_cast<unsigned long long*>(a.partial) + (size_t)blockIdx.x * 32 : nullptr;
   int nstamp = 0;
   auto stamp = [&]() {
     if (dbg && c.tid == 0 && nstamp < 5) {
@@ -452,6 +470,11 @@ __global__ __launch_bounds__(256, 2) void conv3_flat_kernel(const sda_conv_args 
     dbg[3] = (unsigned long long)u;
   }
   stamp();
+  if constexpr (STAMP) {       // only 256-row tiles are stamped; sums land behind the wall-clock stamps of this workgroup
+    if (dbg && c.tid == 0) { for (int i = 0; i < 5; ++i) dbg[16 + i] = 0; }
+    for (int p = 0; p < pairs; ++p, u += 2) { flat_tile<E, BN, 8, RESX, true>(a, smem, c, (long)u * F_UNIT, u, dbg ? dbg + 16 : nullptr); stamp(); }
+    return;
+  }
   if (lead) { flat_tile<E, BN, 4, RESX>(a, smem, c, (long)u * F_UNIT, u); ++u; stamp(); }
   for (int p = 0; p < pairs; ++p, u += 2) { flat_tile<E, BN, 8, RESX>(a, smem, c, (long)u * F_UNIT, u); stamp(); }
   if (tail) { flat_tile<E, BN, 4, RESX>(a, smem, c, (long)u * F_UNIT, u); stamp(); }
@@ -483,10 +506,10 @@ FlatPlan flat_plan(const sda_conv_args& a) {
   return p;
 }
 
-template <typename E, bool BN, bool RESX>
+template <typename E, bool BN, bool RESX, bool STAMP = false>
 int launch_flat(const sda_conv_args& a, hipStream_t st) {
   static bool attr_done = false;
-  auto kern = conv3_flat_kernel<E, BN, RESX>;
+  auto kern = conv3_flat_kernel<E, BN, RESX, STAMP>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS) != hipSuccess) {
       set_error("conv3_flat: cannot reserve %d bytes of LDS", F_LDS);
@@ -518,6 +541,7 @@ template <typename E> static int launch_flat_e(const sda_conv_args& a, hipStream
 }
 
 int launch_conv3_flat(const sda_conv_args& a, hipStream_t st) {
+  if ((a.flags & 128) && (a.flags & 32) && a.dtype == SDA_BF16 && !a.bn_x && !a.res) return launch_flat<uint16_t, false, false, true>(a, st);   // diagnostic
   if (a.dtype == SDA_F32) return launch_flat_e<float>(a, st);
   if (a.dtype == SDA_F16) return launch_flat_e<half_t>(a, st);
   return launch_flat_e<uint16_t>(a, st);

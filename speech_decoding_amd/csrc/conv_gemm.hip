@@ -51,7 +51,11 @@ template <> __device__ inline float4 round_like<uint16_t>(float4 v) {
 // NT = number of 128-row output tiles one workgroup computes SIDE BY SIDE against the same weight slab
 // (4 waves per tile).  The weight slab is 3/4 of the bytes a workgroup pulls through LDS per K-step, so
 // NT = 2 cuts the L2->LDS traffic per FLOP by 37 %: the main loop is LDS-DMA bound, not MFMA bound.
-template <typename E, int TILE_CO, int KS, int NT, bool BN = false>
+// SV: row-layout operands with fully padded weights (every launch except the split-K "matrix mode"): each 1 KB LDS-DMA
+// piece starts at a wave-uniform row, so its address is a scalar base + ONE per-lane offset register (lds_dma16_sv) and the
+// per-piece arithmetic runs on the scalar unit — with per-lane 64-bit addresses the staging cost ~100 VALU instructions
+// per K-step and wave, a third of the MFMA time beside it.
+template <typename E, int TILE_CO, int KS, int NT, bool BN = false, bool SV = true>
 __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_args a, const int n_t_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SLAB = ROW_B / (int)sizeof(E);          // input channels per LDS row / K-step
@@ -120,34 +124,43 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
   // tile's input rows; all NW waves share the weight pieces, issued tap by tap between MFMA groups.
   const int prow = lane >> 2;                                   // row within the piece
   const int pchunk = lane & 3;                                  // physical chunk written by this lane
+  // SV: per-lane byte offsets inside a piece (the swizzle depends on bit 2 of the row: pieces start at multiples of 16
+  // rows and TILE_CO is a multiple of 32, so it is the same for every piece)
+  const uint32_t xvoff = (uint32_t)(((size_t)prow * a.x_pitch + (size_t)((pchunk ^ sw64(prow)) * PER16)) * sizeof(E));
+  const uint32_t wvoff = (uint32_t)(((size_t)prow * a.w_pitch + (size_t)((pchunk ^ sw64(prow)) * PER16)) * sizeof(E));
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  auto dma_x = [&](int s, int p, uint32_t lds_off) {           // input piece p (16 rows) of K-step s
+    if constexpr (SV) {
+      long srow = row_base + p * 16;
+      srow = srow < 0 ? 0 : (srow > a.x_rows_limit - 16 ? a.x_rows_limit - 16 : srow);   // (never taken in row layout: slack rows)
+      lds_dma16_sv(xg + (size_t)srow * a.x_pitch + (size_t)s * SLAB, xvoff, lds_base + lds_off);
+    } else {
+      const int r = p * 16 + prow;
+      long row = row_base + r;
+      row = row < 0 ? 0 : (row >= a.x_rows_limit ? a.x_rows_limit - 1 : row);
+      lds_dma16(xg + (size_t)row * a.x_pitch + (size_t)s * SLAB + (pchunk ^ sw64(r)) * PER16, lds_base + lds_off);
+    }
+  };
+  auto dma_w = [&](int s, int tap, int q, uint32_t lds_off) {  // weight piece q (16 output channels) of one tap
+    if constexpr (SV) {
+      lds_dma16_sv(wg + ((size_t)tap * a.Cout_p + co0 + q * 16) * a.w_pitch + (size_t)s * SLAB, wvoff, lds_base + lds_off);
+    } else {
+      int co = co0 + q * 16 + prow;
+      co = co < a.w_rows_limit ? co : a.w_rows_limit - 1;
+      lds_dma16(wg + ((size_t)tap * a.Cout_p + co) * a.w_pitch + (size_t)s * SLAB + (pchunk ^ sw64(q * 16 + prow)) * PER16,
+                lds_base + lds_off);
+    }
+  };
   auto stage_x = [&](int s, int buf) {
-    unsigned char* xs = smem + buf * STAGE + tsel * XS_BYTES;
-    const size_t koff = (size_t)s * SLAB;
     if (tile_ok) {
-      for (int p = wid & 3; p < x_pieces; p += 4) {
-        const int r = p * 16 + prow;
-        long row = row_base + r;
-        row = row < 0 ? 0 : (row >= a.x_rows_limit ? a.x_rows_limit - 1 : row);
-        const int lc = pchunk ^ sw64(r);
-        lds_dma16(xg + (size_t)row * a.x_pitch + koff + lc * PER16,
-                  __builtin_amdgcn_readfirstlane(lds_addr(xs + p * 1024)));
-      }
+      for (int p = wid & 3; p < x_pieces; p += 4) dma_x(s, p, buf * STAGE + tsel * XS_BYTES + p * 1024);
     }
   };
   auto stage_w = [&](int s, int buf, int tap) {          // the TILE_CO rows of one tap
-    unsigned char* ws = smem + buf * STAGE + NT * XS_BYTES;
-    const size_t koff = (size_t)s * SLAB;
 #pragma unroll
     for (int i = 0; i < (TP + NW - 1) / NW; ++i) {
       const int q = wid + i * NW;
-      if (q < TP) {
-        const int r = tap * TILE_CO + q * 16 + prow;      // row of the [tap][co] weight image
-        int co = co0 + q * 16 + prow;
-        co = co < a.w_rows_limit ? co : a.w_rows_limit - 1;
-        const int lc = pchunk ^ sw64(r);
-        lds_dma16(wg + ((size_t)tap * a.Cout_p + co) * a.w_pitch + koff + lc * PER16,
-                  __builtin_amdgcn_readfirstlane(lds_addr(ws + (tap * TP + q) * 1024)));
-      }
+      if (q < TP) dma_w(s, tap, q, buf * STAGE + NT * XS_BYTES + (tap * TP + q) * 1024);
     }
   };
 
@@ -197,31 +210,18 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
     constexpr int WQ = 4;                                 // weight pieces per wave per slab: KS*TP = 30 <= 8*4
     static_assert(KS * TP <= NW * WQ, "weight pieces do not fit the fixed per-wave DMA count");
     auto stage3_x = [&](int s, int buf) {
-      unsigned char* xs = smem + buf * STAGE + tsel * XS_BYTES;
-      const size_t koff = (size_t)s * SLAB;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         int p = (wid & 3) + 4 * i;
         p = p < x_pieces ? p : x_pieces - 1;
-        const int r = p * 16 + prow;
-        long row = row_base + r;
-        row = row < 0 ? 0 : (row >= a.x_rows_limit ? a.x_rows_limit - 1 : row);
-        const int lc = pchunk ^ sw64(r);
-        lds_dma16(xg + (size_t)row * a.x_pitch + koff + lc * PER16,
-                  __builtin_amdgcn_readfirstlane(lds_addr(xs + p * 1024)));
+        dma_x(s, p, buf * STAGE + tsel * XS_BYTES + p * 1024);
       }
     };
     auto stage3_w = [&](int s, int buf, int i) {          // i-th of this wave's WQ weight pieces
-      unsigned char* ws = smem + buf * STAGE + NT * XS_BYTES;
-      const size_t koff = (size_t)s * SLAB;
       int q = wid + NW * i;
       q = q < KS * TP ? q : KS * TP - 1;
       const int tap = q / TP;
-      const int r = q * 16 + prow;                        // row of the [tap][co] weight image (= tap*TILE_CO + ...)
-      const int co = co0 + (q - tap * TP) * 16 + prow;
-      const int lc = pchunk ^ sw64(r);
-      lds_dma16(wg + ((size_t)tap * a.Cout_p + co) * a.w_pitch + koff + lc * PER16,
-                  __builtin_amdgcn_readfirstlane(lds_addr(ws + q * 1024)));
+      dma_w(s, tap, q - tap * TP, buf * STAGE + NT * XS_BYTES + q * 1024);
     };
     auto stage3 = [&](int s, int buf) {
       stage3_x(s, buf);
@@ -416,11 +416,11 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
   }
 }
 
-template <typename E, int TILE_CO, int KS, int NT, bool BN = false>
+template <typename E, int TILE_CO, int KS, int NT, bool BN = false, bool SV = true>
 static int launch_conv(const sda_conv_args& a, hipStream_t st) {
   constexpr int lds = conv_lds_bytes<TILE_CO, KS, NT>();
   static bool attr_done = false;
-  auto kern = conv_gemm_kernel<E, TILE_CO, KS, NT, BN>;
+  auto kern = conv_gemm_kernel<E, TILE_CO, KS, NT, BN, SV>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             lds) != hipSuccess) {
@@ -448,8 +448,17 @@ static int dispatch_conv_nt(const sda_conv_args& a, hipStream_t st) {
   const bool pair = !a.widx && a.ksplit == 1 && (a.flags & SDA_CONV_PAIR_TILES) && !(a.flags & SDA_CONV_SINGLE_TILE);
   if (a.bn_x) {                 // BatchNorm-backward statistics epilogue: data-gradient convs of the k = 3 layers
     if (!k3) { set_error("conv_gemm: bn_x is built for kernel size 3 only"); return -1; }
-    return pair ? launch_conv<E, TILE_CO, 3, 2, true>(a, st) : launch_conv<E, TILE_CO, 3, 1, true>(a, st);
   }
+  // scalar-base DMA needs whole 16-row pieces inside the operands: row-layout activations (slack rows behind the last
+  // sample) and fully padded weights; the split-K matrix mode (plain matrices, ragged row counts) keeps per-lane addresses
+  const bool sv = a.x_row0 >= PAD && a.x_sample_rows >= a.T + PAD && a.w_rows_limit >= a.Cout_p && !a.partial &&
+                  a.x_rows_limit >= a.x_row0 + (long)(a.B - 1) * a.x_sample_rows + (long)n_t * TILE_T + 2 * PAD &&
+                  (long)a.x_pitch * 16 * (long)sizeof(E) < (1L << 31) && (long)a.w_pitch * 16 * (long)sizeof(E) < (1L << 31);
+  if (!sv) {
+    if (k3 || pair) { set_error("conv_gemm: kernel-3 / paired-tile launches need row-layout operands"); return -1; }
+    return launch_conv<E, TILE_CO, 1, 1, false, false>(a, st);
+  }
+  if (a.bn_x) return pair ? launch_conv<E, TILE_CO, 3, 2, true>(a, st) : launch_conv<E, TILE_CO, 3, 1, true>(a, st);
   if (pair) return k3 ? launch_conv<E, TILE_CO, 3, 2>(a, st) : launch_conv<E, TILE_CO, 1, 2>(a, st);
   return k3 ? launch_conv<E, TILE_CO, 3, 1>(a, st) : launch_conv<E, TILE_CO, 1, 1>(a, st);
 }

@@ -230,7 +230,8 @@ __device__ inline float wave_max(float v) {
 // first read — which serialises the copy of slab s+1 against the MFMAs of slab s.  The asm form is invisible
 // to that bookkeeping: completion is enforced by OUR counted s_waitcnt vmcnt(N) + barrier.
 //   gsrc: this lane's 16 source bytes; lds_dst: wave-uniform LDS byte address; lane l lands at lds_dst + 16*l.
-__device__ inline void lds_dma16(const void* gsrc, uint32_t lds_dst) {
+__device__ inline void lds_dma16(const void* gsrc, uint32_t lds_dst_in) {
+  const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_in);   // wave-uniform by contract
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
@@ -240,7 +241,8 @@ __device__ inline void lds_dma16(const void* gsrc, uint32_t lds_dst) {
 // The same with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset: when
 // the piece's row is wave-uniform all per-piece arithmetic is scalar and ONE offset register serves every piece.
 // (s_nop 4: a base that was just produced by v_readfirstlane needs 5 wait states before a VMEM instruction reads it.)
-__device__ inline void lds_dma16_sv(const void* sbase_in, uint32_t voff, uint32_t lds_dst) {
+__device__ inline void lds_dma16_sv(const void* sbase_in, uint32_t voff, uint32_t lds_dst_in) {
+  const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_in);
   // the base IS wave-uniform by construction; where hipcc cannot prove it, make it provable (folds away where it can)
   const uint64_t sb64 = (uint64_t)(uintptr_t)sbase_in;
   // (the builtin returns int: go through uint32_t, or an address with bit 31 set sign-extends into the high half)

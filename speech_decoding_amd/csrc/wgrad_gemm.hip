@@ -169,9 +169,15 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
   // one K-chunk = KT rows of one sample.  DMA pieces are 1 KB, lane-linear in LDS; each lane derives the
   // (row, chunk) its 16 bytes belong to and fetches the swizzle-matched source chunk.  dy rows at t >= T
   // come from a guaranteed-zero row (they must not contribute); x rows are merely clamped into the buffer.
+  // (the sample index is read from `perm` once per SAMPLE: a global load in the chunk loop is waited for with vmcnt(0))
+  int staged_si = -1, staged_b = 0;
   auto stage = [&](int it, int buf) {
     const int si = it / nchunk, ch = it - si * nchunk;
-    const int b = a.perm ? a.perm[s_beg + si] : (s_beg + si);
+    if (si != staged_si) {
+      staged_si = si;
+      staged_b = a.perm ? __builtin_amdgcn_readfirstlane(a.perm[s_beg + si]) : (s_beg + si);
+    }
+    const int b = staged_b;
     const long srow = a.row0 + (long)b * a.sample_rows;
     const int t0 = ch * KT;
     unsigned char* dys = smem + buf * G::STAGE;

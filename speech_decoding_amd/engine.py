@@ -143,8 +143,8 @@ class EncoderEngine:
         key = (B, nseg, str(device))
         if key not in self._seg_cache:
             edges = np.floor(np.linspace(0, B, nseg + 1)).astype(np.int32)
-            self._seg_cache[key] = (torch.arange(B, dtype=torch.int32, device=device),
-                                    torch.from_numpy(edges).to(device))
+            # (no permutation: consecutive samples; the kernel then needs no index load in its chunk loop)
+            self._seg_cache[key] = (None, torch.from_numpy(edges).to(device))
         perm, seg = self._seg_cache[key]
         return perm, seg, nseg
 

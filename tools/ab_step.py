@@ -40,19 +40,26 @@ def timed(n=10):
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
+# variants: name:attr=value,attr=value ... (engine attributes; values are Python literals)
+specs = sys.argv[2:] or ["base:", "flat_fwd_off:flat_tiles_forward=False"]
 variants = {}
-for name in sys.argv[2:] or ["base", "flat_fwd", "flat_both", "flat_both_1cu"]:
-    variants[name] = dict(base=(False, False, False), flat_fwd=(True, False, False), flat_bwd=(False, True, False), flat_both=(True, True, False),
-                          flat_both_1cu=(True, True, True), flat_bwd_1cu=(False, True, True))[name]
+for spec in specs:
+    name, _, rest = spec.partition(":")
+    variants[name] = {kv.split("=")[0]: eval(kv.split("=")[1]) for kv in rest.split(",") if kv}
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 eng = enc.engine
+defaults = {k: getattr(eng, k) for v in variants.values() for k in v}
+def apply(v):
+    for k, d in defaults.items(): setattr(eng, k, d)
+    for k, x in v.items(): setattr(eng, k, x)
+    eng._seg_cache.clear()
 res = {k: [] for k in variants}
-for k, (f, b, o) in variants.items():           # warm-up of every variant (workspaces, attribute calls)
-    eng.flat_tiles_forward, eng.flat_tiles_backward, eng.flat_backward_one_per_cu = f, b, o
+for k, v in variants.items():           # warm-up of every variant (workspaces, attribute calls)
+    apply(v)
     for _ in range(3): step()
 for r in range(rounds):
-    for k, (f, b, o) in variants.items():
-        eng.flat_tiles_forward, eng.flat_tiles_backward, eng.flat_backward_one_per_cu = f, b, o
+    for k, v in variants.items():
+        apply(v)
         res[k].append(timed())
 for k, v in res.items():
     print(f"{k:10s} median {np.median(v):.3f} ms  min {min(v):.3f}  all {[round(x, 3) for x in v]}")

@@ -50,6 +50,8 @@ def main():
                 seg = torch.from_numpy(np.floor(np.linspace(0, B, nseg + 1)).astype(np.int32)).to(dev)
                 perm = torch.arange(B, dtype=torch.int32, device=dev)
                 us = timeit(lambda: ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=perm, seg_start=seg, nseg=nseg))
+                print(f"wgrad(perm) {str(dtype)[6:]:8s} {cin}->{cout} k{KS} nseg={nseg:3d} {us:8.1f} us  {fl/us/1e6:7.1f} TF", flush=True)
+                us = timeit(lambda: ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=None, seg_start=seg, nseg=nseg))
                 print(f"wgrad {str(dtype)[6:]:8s} {cin}->{cout} k{KS} nseg={nseg:3d} {us:8.1f} us  {fl/us/1e6:7.1f} TF", flush=True)
 
 if __name__ == "__main__":

@@ -20,7 +20,7 @@ def main():
     y = ops.new_rows(B, T, cout, dtype, dev)
     bias = torch.zeros(cout, device=dev)
     stats = torch.zeros((ops.conv_stats_rows(B, T, 3, cout, 16384), 2, cout), device=dev)
-    dbg = torch.zeros((1024, 16), dtype=torch.int64, device=dev)
+    dbg = torch.zeros((1024, 32), dtype=torch.int64, device=dev)
 
     def run(flags, use_dbg):
         a = L.ConvArgs()
@@ -75,6 +75,15 @@ def main():
         if pp[0] == pp[1]: same += 1
         else: diff += 1
     print(f"places with two workgroups: same plan {same}, different plans {diff}")
+    if extra & 128:
+        seg = d[:, 16:21].astype(np.float64)
+        seg = seg[seg[:, 4] > 0]
+        per = seg[:, :4] / seg[:, 4:5]
+        names = ["barrier exit -> operands in registers", "MFMA + DMA issue", "vmcnt wait", "barrier"]
+        print(f"K-loop phases of the stamped build ({int(np.median(seg[:, 4]))} phases per workgroup), cycles per phase (median over workgroups):")
+        for i, nme in enumerate(names):
+            print(f"   {nme:40s} {np.median(per[:, i]):8.0f}")
+        print(f"   {'sum':40s} {np.median(per.sum(axis=1)):8.0f}")
 
 if __name__ == "__main__":
     main()
