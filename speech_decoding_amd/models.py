@@ -296,10 +296,14 @@ class Classifier(nn.Module):
         self.global_candidates = True       # under torch.distributed: rank against the global batch
 
     @torch.no_grad()
-    def forward(self, Z: torch.Tensor, Y: torch.Tensor, test: bool = False):
-        B = Z.size(0)
-        if B < 10:
+    def ranks(self, Z: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+        """Rank of every speech row's own brain column (0 = top-1) as a DEVICE tensor: what forward() reduces to the two
+        accuracies, without the host read-back (a training loop can collect these and read them once per epoch)."""
+        if Z.size(0) < 10:
             raise RuntimeError("selected index k out of range")      # torch.topk(…, 10) on fewer than 10 columns
-        cnt = _loss.retrieval_ranks(Y, Z, self.global_candidates)
-        cnt = cnt.cpu().numpy()
+        return _loss.retrieval_ranks(Y, Z, self.global_candidates)
+
+    @torch.no_grad()
+    def forward(self, Z: torch.Tensor, Y: torch.Tensor, test: bool = False):
+        cnt = self.ranks(Z, Y).cpu().numpy()
         return float((cnt == 0).mean()), np.mean(cnt < 10)
