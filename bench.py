@@ -164,7 +164,9 @@ def pmc_traffic(dtype: str, tile_co: int, ks: int, kind: str = "conv_gemm"):
         return None, None
     kernels = json.load(open(files[-1])).get("kernels", {})
     ctype = {"bf16": "unsigned short", "fp16": "_Float16", "fp32": "float"}[dtype]
-    hits = [v for k, v in kernels.items() if f"{kind}" in k and f"<{ctype}, {tile_co}, {ks}," in k]
+    hits = [v for k, v in kernels.items() if f"{kind}_kernel<{ctype}, {tile_co}, {ks}," in k]
+    if kind == "conv_gemm" and ks == 3 and tile_co == 160:          # the same family's flat-tile instantiations (conv3_flat.hip)
+        hits += [v for k, v in kernels.items() if f"conv3_flat_kernel<{ctype}," in k]
     if not hits:
         return None, os.path.relpath(files[-1], ROOT)
     n = sum(h["launches"] for h in hits)
