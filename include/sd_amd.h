@@ -36,6 +36,10 @@ enum { SDA_F32 = 0, SDA_BF16 = 1, SDA_F16 = 2 };   /* storage + MFMA operand typ
 
 /* conv_gemm epilogue flags */
 enum { SDA_EPI_GELU = 1,
+       SDA_EPI_GLU = 2,             /* with SDA_CONV_FLAT_TILES: the conv's Cout_p = 2 * Hp channels are [value | gate] pairs
+                                       laid out per 160-channel tile as 80 value + 80 gate channels (weights and bias packed with
+                                       glu_tile = 80); y [rows][Hp] = value * sigmoid(gate) (models.py:164, F.glu), both as
+                                       rounded to the storage type; y_pre [rows][Hp] = gate, or NULL.  No res / stats / bn_x */
        SDA_CONV_SINGLE_TILE = 4096, /* force one 128-row tile per workgroup */
        SDA_CONV_PAIR_TILES = 8192,  /* two tiles per workgroup sharing one weight slab (default: one) */
        SDA_CONV_ONE_PER_CU = 32768, /* with SDA_CONV_FLAT_TILES: at most one workgroup per CU (half the LDS stays free) */
@@ -77,6 +81,8 @@ typedef struct sda_pack_desc {
   const float* src;
   void* dst;
   int nW, Cout, Cin, KS, Cout_p, Cin_p, mode, glu_half, glu_half_p, is_vector;
+  int glu_tile;   /* 0: the two GLU halves stay contiguous ([0, glu_half_p) values, then gates); 80: SDA_EPI_GLU's layout —
+                   * packed output channel 160 j + w is value channel 80 j + w (w < 80) or gate channel 80 j + w - 80 */
   long total;
 } sda_pack_desc;
 int sda_pack_multi(const sda_pack_desc* descs, int n, long max_total, int dtype, void* stream);
@@ -113,8 +119,8 @@ typedef struct sda_conv_args {
   const void* w;        /* packed [nW][KS][Cout_p][w_pitch] */
   const float* bias;    /* [Cout_p] or NULL */
   const void* res;      /* RL [rows][Cout_p] residual added in the epilogue, or NULL */
-  void* y;              /* RL [rows][Cout_p] output (post-activation when SDA_EPI_GELU) */
-  void* y_pre;          /* with SDA_EPI_GELU: pre-activation output, or NULL */
+  void* y;              /* RL [rows][Cout_p] output (post-activation when SDA_EPI_GELU; [rows][Cout_p / 2] with SDA_EPI_GLU) */
+  void* y_pre;          /* with SDA_EPI_GELU: pre-activation output, or NULL; with SDA_EPI_GLU: the gate, or NULL */
   const int32_t* widx;  /* [B] weight selector per sample (device), or NULL */
   float* stats;         /* [B * n_t_tiles][2][Cout_p] per-tile (sum, sum of squares) over valid rows, or NULL */
   float* partial;       /* ksplit > 1: [ksplit][T][Cout_p] fp32 raw accumulators (B must be 1) */
@@ -182,6 +188,10 @@ int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, float* cols
                             int Ch, int dtype, void* stream);
 int sda_gelu_backward_colsum(const void* u, const void* dz, void* du, float* colsum, float* scratch, int B, int T,
                              int Cp, int dtype, void* stream);
+/* GLU backward after a forward with SDA_EPI_GLU (the value half was never stored): out = value * sigmoid(gate) and gate,
+ * both RL [rows][Ch]; dx RL [rows][2*Ch] = [d value | d gate] = [dy * sig(g) | dy * out * (1 - sig(g))]; colsum as above */
+int sda_glu_backward_colsum_og(const void* out, const void* gate, const void* dy, void* dx, float* colsum, float* scratch,
+                               int B, int T, int Ch, int dtype, void* stream);
 /* column sums of an RL tensor over valid rows: out[c] = sum_{b,t} x[b,t,c]  (bias gradients) */
 int sda_colsum(const void* x, float* out, float* scratch /* sda_reduce_scratch_floats(Cp) */, int B, int T,
                int Cp, int dtype, void* stream);

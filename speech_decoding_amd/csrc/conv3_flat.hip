@@ -58,6 +58,11 @@ template <int CH> struct FEpi {
   static constexpr int ITERS = (F_EP_ROWS + RG - 1) / RG;
   static constexpr int RED_BYTES = RG * F_CO * 2 * 4;
 };
+template <int CH> struct FEpiGlu {                   // SDA_EPI_GLU: a row of the tile is 80 value + 80 gate channels
+  static constexpr int NCH = F_CO / 2 / CH;          // CH-channel chunks of the 80 output channels
+  static constexpr int RG = 256 / NCH;
+  static constexpr int ITERS = (F_EP_ROWS + RG - 1) / RG;
+};
 constexpr int F_LDS = F_MAIN;
 static_assert(F_EP_BYTES + FEpi<4>::RED_BYTES <= F_LDS && F_EP_BYTES + FEpi<8>::RED_BYTES <= F_LDS, "epilogue staging must fit");
 static_assert(2 * F_LDS <= 160 * 1024, "two workgroups per CU");
@@ -113,7 +118,7 @@ struct FTileCtx {            // per-workgroup constants shared by all its tiles
 // STAMP (diagnostic build, never the product path): s_memtime stamps split every tap phase of the K loop into
 // [barrier exit -> operands in registers] [MFMA + DMA issue] [vmcnt wait] [barrier]; the four cycle sums of wave 0 go to
 // st[0..3] (+ the phase count in st[4]).  Shares are meaningful, the run time of this build is not.
-template <typename E, bool BN, int MREP, bool RESX, bool STAMP = false>
+template <typename E, bool BN, int MREP, bool RESX, bool STAMP = false, bool GLU = false>
 __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char* smem, const FTileCtx& c, const long f0,
                                           const int stat_row, unsigned long long* st = nullptr) {
   constexpr int SLAB = ROW_B / (int)sizeof(E);
@@ -311,6 +316,36 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
     }
     if constexpr (RES_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's residual pieces have landed
     __syncthreads();
+    if constexpr (GLU) {
+      // F.glu (models.py:164) on the staged slice: columns [0, 80) are values, [80, 160) their gates; both are rounded to the
+      // storage type first, so the result is bit-equal to conv -> store -> glu_fwd_kernel; the gate is kept for backward
+      using GG = FEpiGlu<CH>;
+      const int gch = tid % GG::NCH, grg = tid / GG::NCH;
+      const int Hp = a.Cout_p / 2, ho0 = co0 / 2;
+      E* __restrict__ gateg = reinterpret_cast<E*>(a.y_pre);
+      int p = (int)(((unsigned)(f0 + q * F_EP_ROWS) + (unsigned)grg) % (unsigned)Tp);
+#pragma unroll
+      for (int it = 0; it < GG::ITERS; ++it) {
+        const int row = grg + it * GG::RG;
+        if (grg < GG::RG && row < F_EP_ROWS && p >= PAD && f0 + q * F_EP_ROWS + row < c.total_rows) {
+          float v[CH], g[CH];
+#pragma unroll
+          for (int q4 = 0; q4 < CH / 4; ++q4) {
+            const float4 f = *reinterpret_cast<const float4*>(ep + row * F_STRIDE + gch * CH + q4 * 4);
+            const float4 h = *reinterpret_cast<const float4*>(ep + row * F_STRIDE + F_CO / 2 + gch * CH + q4 * 4);
+            v[q4 * 4 + 0] = f.x; v[q4 * 4 + 1] = f.y; v[q4 * 4 + 2] = f.z; v[q4 * 4 + 3] = f.w;
+            g[q4 * 4 + 0] = h.x; g[q4 * 4 + 1] = h.y; g[q4 * 4 + 2] = h.z; g[q4 * 4 + 3] = h.w;
+          }
+          const size_t off = (size_t)(f0 + q * F_EP_ROWS + row) * Hp + ho0 + gch * CH;
+          if (gateg) Vec16<E>::store(gateg + off, g);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) v[j] = Vec16<E>::round(v[j]) * sigmoid_f(Vec16<E>::round(g[j]));
+          Vec16<E>::store(yg + off, v);
+        }
+        p += GG::RG;
+        while (p >= Tp) p -= Tp;
+      }
+    } else
     // this thread's rows of the slice (BatchNorm-input rows are fetched one row ahead, packed; the accumulators of the
     // later slices are still live here: no register may spill — a scratch reload waits for every store in flight)
     {
@@ -399,7 +434,7 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
   __syncthreads();            // the next tile's LDS-DMA overwrites the staging / reduction area
 }
 
-template <typename E, bool BN, bool RESX, bool STAMP = false>
+template <typename E, bool BN, bool RESX, bool STAMP = false, bool GLU = false>
 __global__ __launch_bounds__(256, 2) void conv3_flat_kernel(const sda_conv_args a, const int n_units, const int units_per_wg,
                                                             const int runs_per_co, const long total_rows, const int Tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -475,9 +510,9 @@ __global__ __launch_bounds__(256, 2) void conv3_flat_kernel(const sda_conv_args 
     for (int p = 0; p < pairs; ++p, u += 2) { flat_tile<E, BN, 8, RESX, true>(a, smem, c, (long)u * F_UNIT, u, dbg ? dbg + 16 : nullptr); stamp(); }
     return;
   }
-  if (lead) { flat_tile<E, BN, 4, RESX>(a, smem, c, (long)u * F_UNIT, u); ++u; stamp(); }
-  for (int p = 0; p < pairs; ++p, u += 2) { flat_tile<E, BN, 8, RESX>(a, smem, c, (long)u * F_UNIT, u); stamp(); }
-  if (tail) { flat_tile<E, BN, 4, RESX>(a, smem, c, (long)u * F_UNIT, u); stamp(); }
+  if (lead) { flat_tile<E, BN, 4, RESX, false, GLU>(a, smem, c, (long)u * F_UNIT, u); ++u; stamp(); }
+  for (int p = 0; p < pairs; ++p, u += 2) { flat_tile<E, BN, 8, RESX, false, GLU>(a, smem, c, (long)u * F_UNIT, u); stamp(); }
+  if (tail) { flat_tile<E, BN, 4, RESX, false, GLU>(a, smem, c, (long)u * F_UNIT, u); stamp(); }
 }
 
 struct FlatPlan { int n_units, units_per_wg, runs_per_co, grid; };
@@ -506,10 +541,10 @@ FlatPlan flat_plan(const sda_conv_args& a) {
   return p;
 }
 
-template <typename E, bool BN, bool RESX, bool STAMP = false>
+template <typename E, bool BN, bool RESX, bool STAMP = false, bool GLU = false>
 int launch_flat(const sda_conv_args& a, hipStream_t st) {
   static bool attr_done = false;
-  auto kern = conv3_flat_kernel<E, BN, RESX, STAMP>;
+  auto kern = conv3_flat_kernel<E, BN, RESX, STAMP, GLU>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS) != hipSuccess) {
       set_error("conv3_flat: cannot reserve %d bytes of LDS", F_LDS);
@@ -528,7 +563,9 @@ int launch_flat(const sda_conv_args& a, hipStream_t st) {
 int conv3_flat_stat_rows(int B, int T) { return (int)(((long)B * rows_tp(T) + F_UNIT - 1) / F_UNIT); }
 
 bool conv3_flat_supports(const sda_conv_args& a) {
-  return a.KS == 3 && a.Cout_p % F_CO == 0 && !a.widx && a.ksplit == 1 && (!a.partial || (a.flags & 32)) && !(a.flags & SDA_EPI_GELU) && !a.y_pre &&
+  const bool glu = a.flags & SDA_EPI_GLU;
+  if (glu ? (a.res || a.stats || a.bn_x) : a.y_pre != nullptr) return false;
+  return a.KS == 3 && a.Cout_p % F_CO == 0 && !a.widx && a.ksplit == 1 && (!a.partial || (a.flags & 32)) && !(a.flags & SDA_EPI_GELU) &&
          a.y && a.x_row0 == PAD && a.x_sample_rows == rows_tp(a.T) && (!a.bn_x || (a.bn_coef && a.stats)) &&
 
          a.x_rows_limit >= (long)a.B * rows_tp(a.T) + 3 * PAD && a.x_rows_limit < (1L << 31) && a.w_rows_limit >= a.Cout_p &&
@@ -536,6 +573,7 @@ bool conv3_flat_supports(const sda_conv_args& a) {
 }
 
 template <typename E> static int launch_flat_e(const sda_conv_args& a, hipStream_t st) {
+  if (a.flags & SDA_EPI_GLU) return launch_flat<E, false, false, false, true>(a, st);
   if (a.bn_x) return a.res ? launch_flat<E, true, true>(a, st) : launch_flat<E, true, false>(a, st);
   return a.res ? launch_flat<E, false, true>(a, st) : launch_flat<E, false, false>(a, st);
 }

@@ -470,6 +470,7 @@ static int dispatch_conv(const sda_conv_args& a, hipStream_t st) {
     if (!conv3_flat_supports(a)) { set_error("conv_gemm: SDA_CONV_FLAT_TILES needs a plain row-layout kernel-3 convolution"); return -1; }
     return launch_conv3_flat(a, st);
   }
+  if (a.flags & SDA_EPI_GLU) { set_error("conv_gemm: SDA_EPI_GLU needs SDA_CONV_FLAT_TILES, kernel size 3 and Cout_p % 160 == 0"); return -1; }
   if (a.Cout_p % 160 == 0) return dispatch_conv_nt<E, 160>(a, st);
   if (a.Cout_p % 128 == 0) return dispatch_conv_nt<E, 128>(a, st);
   return dispatch_conv_nt<E, 64>(a, st);

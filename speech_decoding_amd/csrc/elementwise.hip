@@ -9,6 +9,43 @@
 namespace sda {
 
 // ------------------------------------------------------------------------------------------------
+// Row streaming skeleton of the elementwise passes.  A thread OWNS one 16-byte channel chunk (its per-channel
+// coefficients stay in registers) and walks the valid rows of its workgroup's contiguous row range with stride RG =
+// 256 / chunks-per-row; (sample, time) advance incrementally, so the loop has no integer division and no
+// coefficient loads — with both, the BatchNorm/GELU passes were VALU-bound (≈ 4.3 TB/s), not HBM-bound.
+// Rows are taken U at a time: all loads of a batch are issued before the first use.
+// ------------------------------------------------------------------------------------------------
+struct RowWalk {
+  int r, r1, step, T, b, t;
+  __device__ RowWalk(int r0, int r1_, int step_, int T_) : r(r0), r1(r1_), step(step_), T(T_) {
+    b = r0 / T_;
+    t = r0 - b * T_;
+  }
+  __device__ bool valid() const { return r < r1; }
+  __device__ size_t mem_row() const { return (size_t)b * rows_tp(T) + PAD + t; }
+  __device__ void next() {
+    r += step; t += step;
+    while (t >= T) { t -= T; ++b; }
+  }
+};
+
+// valid-row range of this workgroup: rows split evenly over the grid
+__device__ inline void block_rows(int B, int T, int& r0, int& r1) {
+  const int rows = B * T;
+  const int per = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+  r0 = min(rows, (int)blockIdx.x * per);
+  r1 = min(rows, r0 + per);
+}
+
+// grid of a streaming pass: about 32 rows per thread-row group, at most 8 workgroups per CU
+static inline int stream_blocks(int B, int T, int nch) {
+  const long rows = (long)B * T;
+  const int RG = nch >= 256 ? 1 : 256 / nch;
+  long nb = (rows + (long)RG * 8 - 1) / ((long)RG * 8);
+  return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+}
+
+// ------------------------------------------------------------------------------------------------
 // (B, C, T) fp32  <->  RL rows
 // ------------------------------------------------------------------------------------------------
 template <typename E>
@@ -101,8 +138,14 @@ __global__ __launch_bounds__(256) void rows_sumsq_from_stats_kernel(const float*
 // ------------------------------------------------------------------------------------------------
 // weight / vector packing
 // ------------------------------------------------------------------------------------------------
-__device__ inline int glu_unmap(int cop, int Cout, int half, int half_p) {   // packed row -> source row or -1
+__device__ inline int glu_unmap(int cop, int Cout, int half, int half_p, int tile = 0) {   // packed row -> source row or -1
   if (half == 0) return cop < Cout ? cop : -1;
+  if (tile > 0) {                        // SDA_EPI_GLU layout: per 2*tile packed channels, `tile` values then `tile` gates
+    const int j = cop / (2 * tile), w = cop - j * 2 * tile;
+    const int r = j * tile + (w < tile ? w : w - tile);          // channel inside its half
+    if (w < tile) return r < half ? r : -1;
+    return r < Cout - half ? half + r : -1;
+  }
   if (cop < half_p) return cop < half ? cop : -1;
   const int r = cop - half_p;
   return r < Cout - half ? half + r : -1;
@@ -152,7 +195,7 @@ __global__ void pack_multi_kernel(const sda_pack_desc* __restrict__ descs) {
   const size_t total = (size_t)d.total;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     if (d.is_vector) {
-      const int c = glu_unmap((int)i, d.Cout, d.glu_half, d.glu_half_p);
+      const int c = glu_unmap((int)i, d.Cout, d.glu_half, d.glu_half_p, d.glu_tile);
       reinterpret_cast<float*>(d.dst)[i] = c >= 0 ? d.src[c] : 0.f;
       continue;
     }
@@ -160,10 +203,10 @@ __global__ void pack_multi_kernel(const sda_pack_desc* __restrict__ descs) {
     size_t q = i;
     if (d.mode == 0) {
       ci = q % d.Cin_p; q /= d.Cin_p;
-      co = glu_unmap((int)(q % d.Cout_p), d.Cout, d.glu_half, d.glu_half_p); q /= d.Cout_p;
+      co = glu_unmap((int)(q % d.Cout_p), d.Cout, d.glu_half, d.glu_half_p, d.glu_tile); q /= d.Cout_p;
       tap = q % d.KS; q /= d.KS;
     } else {
-      co = glu_unmap((int)(q % d.Cout_p), d.Cout, d.glu_half, d.glu_half_p); q /= d.Cout_p;
+      co = glu_unmap((int)(q % d.Cout_p), d.Cout, d.glu_half, d.glu_half_p, d.glu_tile); q /= d.Cout_p;
       ci = q % d.Cin_p; q /= d.Cin_p;
       tap = d.KS - 1 - (int)(q % d.KS); q /= d.KS;
     }
@@ -298,24 +341,39 @@ template <typename E>
 __global__ __launch_bounds__(256) void bn_gelu_fwd_kernel(const E* __restrict__ x, E* __restrict__ y,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int B, int T, int Cp) {
-  constexpr int CH = Vec16<E>::N;
+  constexpr int CH = Vec16<E>::N, U = 4;
   const int nch = Cp / CH;
-  const size_t total = (size_t)B * T * nch;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ch = i % nch;
-    const size_t vr = i / nch;
-    const int b = vr / T, t = vr - (size_t)b * T;
-    const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * CH;
-    float v[CH], sc[CH], sh[CH];
-    Vec16<E>::load(x + off, v);
+  const int RG = nch >= 256 ? 1 : 256 / nch;
+  int r0, r1;
+  block_rows(B, T, r0, r1);
+  for (int c = threadIdx.x; c < RG * nch; c += 256) {       // one pass unless a row has more than 256 chunks
+    const int ch = c % nch, rg = c / nch;
+    float sc[CH], sh[CH];
 #pragma unroll
-    for (int q4 = 0; q4 < CH / 4; ++q4) {              // per-channel coefficients as 16-byte loads
+    for (int q4 = 0; q4 < CH / 4; ++q4) {
       *reinterpret_cast<float4*>(sc + q4 * 4) = *reinterpret_cast<const float4*>(scale + ch * CH + q4 * 4);
       *reinterpret_cast<float4*>(sh + q4 * 4) = *reinterpret_cast<const float4*>(shift + ch * CH + q4 * 4);
     }
+    RowWalk w(r0 + rg, r1, RG, T);
+    while (w.valid()) {
+      size_t off[U];
+      bool ok[U];
+      float v[U][CH];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) v[j] = gelu_f<E>(v[j] * sc[j] + sh[j]);
-    Vec16<E>::store(y + off, v);
+      for (int u = 0; u < U; ++u) { ok[u] = w.valid(); off[u] = w.mem_row() * Cp + ch * CH; w.next(); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (ok[u]) Vec16<E>::load(x + off[u], v[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int j = 0; j < CH; j += 2) {
+          const f32x2 o = gelu_pair<E>(fma2(f32x2{v[u][j], v[u][j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
+          v[u][j] = o.x; v[u][j + 1] = o.y;
+        }
+        Vec16<E>::store(y + off[u], v[u]);
+      }
+    }
   }
 }
 
@@ -350,9 +408,8 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
       }
     }
 #pragma unroll 2
-    for (size_t r = r0 + rg; r < r1; r += RG) {
-      const int b = r / T, t = r - (size_t)b * T;
-      const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * CH;
+    for (RowWalk w((int)r0 + rg, (int)r1, RG, T); w.valid(); w.next()) {
+      const size_t off = w.mem_row() * Cp + ch * CH;
       float dv[CH];
       Vec16<E>::load(dy + off, dv);
       if (MODE == 0) {
@@ -362,11 +419,12 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
         float xv[CH];
         Vec16<E>::load(x + off, xv);
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          const float xh = (xv[j] - mu[j]) * rs[j];
-          const float dg = dv[j] * gelu_grad_f<E>(ga[j] * xh + be[j]);
-          a0[j] += dg;
-          a1[j] += dg * xh;
+        for (int j = 0; j < CH; j += 2) {
+          const f32x2 xh = (f32x2{xv[j], xv[j + 1]} - f32x2{mu[j], mu[j + 1]}) * f32x2{rs[j], rs[j + 1]};
+          const f32x2 dg = f32x2{dv[j], dv[j + 1]} * gelu_grad_pair<E>(fma2(f32x2{ga[j], ga[j + 1]}, xh, f32x2{be[j], be[j + 1]}));
+          const f32x2 dgx = dg * xh;
+          a0[j] += dg.x; a0[j + 1] += dg.y;
+          a1[j] += dgx.x; a1[j + 1] += dgx.y;
         }
       }
     }
@@ -392,10 +450,12 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
 //   MODE 0 (GELU):  du = dz * GELU'(u);  partial[blk][0][c] = sum du
 //   MODE 1 (GLU):   x = [a | g] (2*Ch channels), dy (Ch): da = dy*sig(g), dg = dy*a*sig(g)*(1-sig(g));
 //                   partial[blk][0][c] = sum da, partial[blk][1][c] = sum dg      (c < Ch)
+//   MODE 2 (GLU after a fused forward, SDA_EPI_GLU): x = out = a*sig(g) (Ch channels), gate = g (Ch channels):
+//                   da = dy*sig(g), dg = dy*out*(1-sig(g)); same outputs as MODE 1 (the value half is never stored)
 template <typename E, int MODE>
 __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x, const E* __restrict__ dy,
                                                          E* __restrict__ dx, float* __restrict__ partial, int B, int T,
-                                                         int Ch) {
+                                                         int Ch, const E* __restrict__ gate = nullptr) {
   extern __shared__ float red[];
   constexpr int CH = Vec16<E>::N;
   const int nch = Ch / CH;
@@ -404,34 +464,38 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
   const size_t rows = (size_t)B * T;
   const size_t per = (rows + gridDim.x - 1) / gridDim.x;
   const size_t r0 = (size_t)blockIdx.x * per, r1 = min(rows, r0 + per);
-  const int xw = MODE == 1 ? 2 * Ch : Ch;
+  const int xw = MODE == 1 ? 2 * Ch : Ch, dxw = MODE == 0 ? Ch : 2 * Ch;
   float a0[CH], a1[CH];
 #pragma unroll
   for (int j = 0; j < CH; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
   if (rg < RG) {
-    for (size_t r = r0 + rg; r < r1; r += RG) {
-      const int b = r / T, t = r - (size_t)b * T;
-      const size_t row = (size_t)b * rows_tp(T) + PAD + t;
+    for (RowWalk w((int)r0 + rg, (int)r1, RG, T); w.valid(); w.next()) {
+      const size_t row = w.mem_row();
       float d[CH], xv[CH], o0[CH], o1[CH];
       Vec16<E>::load(dy + row * Ch + ch * CH, d);
       Vec16<E>::load(x + row * xw + ch * CH, xv);
       if (MODE == 0) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) { o0[j] = d[j] * gelu_grad_f<E>(xv[j]); a0[j] += o0[j]; }
+        for (int j = 0; j < CH; j += 2) {
+          const f32x2 o = f32x2{d[j], d[j + 1]} * gelu_grad_pair<E>(f32x2{xv[j], xv[j + 1]});
+          o0[j] = o.x; o0[j + 1] = o.y;
+          a0[j] += o.x; a0[j + 1] += o.y;
+        }
         Vec16<E>::store(dx + row * Ch + ch * CH, o0);
       } else {
         float g[CH];
-        Vec16<E>::load(x + row * xw + Ch + ch * CH, g);
+        if (MODE == 1) Vec16<E>::load(x + row * xw + Ch + ch * CH, g);
+        else Vec16<E>::load(gate + row * Ch + ch * CH, g);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           const float sg = sigmoid_f(g[j]);
           o0[j] = d[j] * sg;
-          o1[j] = d[j] * xv[j] * sg * (1.f - sg);
+          o1[j] = MODE == 1 ? d[j] * xv[j] * sg * (1.f - sg) : d[j] * xv[j] * (1.f - sg);
           a0[j] += o0[j];
           a1[j] += o1[j];
         }
-        Vec16<E>::store(dx + row * xw + ch * CH, o0);
-        Vec16<E>::store(dx + row * xw + Ch + ch * CH, o1);
+        Vec16<E>::store(dx + row * dxw + ch * CH, o0);
+        Vec16<E>::store(dx + row * dxw + Ch + ch * CH, o1);
       }
     }
   }
@@ -503,30 +567,47 @@ template <typename E>
 __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restrict__ dy, const E* __restrict__ x,
                                                                 const float* __restrict__ coef, E* __restrict__ dx,
                                                                 int B, int T, int Cp) {
-  constexpr int CH = Vec16<E>::N;
+  constexpr int CH = Vec16<E>::N, U = 2;
   const int nch = Cp / CH;
-  const size_t total = (size_t)B * T * nch;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ch = i % nch;
-    const size_t vr = i / nch;
-    const int b = vr / T, t = vr - (size_t)b * T;
-    const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * CH;
-    float d[CH], xv[CH], o[CH], cf[6][CH];
-    Vec16<E>::load(dy + off, d);
-    Vec16<E>::load(x + off, xv);
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-#pragma unroll
-      for (int q4 = 0; q4 < CH / 4; ++q4)                // per-channel coefficients as 16-byte loads
-        *reinterpret_cast<float4*>(&cf[k][q4 * 4]) = *reinterpret_cast<const float4*>(coef + (size_t)k * Cp + ch * CH + q4 * 4);
+  const int RG = nch >= 256 ? 1 : 256 / nch;
+  int r0, r1;
+  block_rows(B, T, r0, r1);
+  for (int c = threadIdx.x; c < RG * nch; c += 256) {
+    const int ch = c % nch, rg = c / nch;
+    // per channel: a = gamma*rstd, b = beta - a*mean (so gamma*xhat + beta = a*x + b), and the linear part of
+    //   dx = gamma*rstd*(g - dbeta/N - xhat*dgamma/N) = a*g - (p + q*x),  q = a*rstd*dgamma/N,  p = a*dbeta/N - q*mean
+    float ca[CH], cb[CH], cp[CH], cq[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const float ga = cf[0][j], be = cf[1][j], mu = cf[2][j], rs = cf[3][j];
-      const float xh = (xv[j] - mu) * rs;
-      const float g = d[j] * gelu_grad_f<E>(ga * xh + be);
-      o[j] = ga * rs * (g - cf[4][j] - xh * cf[5][j]);
+      const int k = ch * CH + j;
+      const float ga = coef[k], be = coef[Cp + k], mu = coef[2 * Cp + k], rs = coef[3 * Cp + k];
+      ca[j] = ga * rs;
+      cb[j] = be - ca[j] * mu;
+      cq[j] = ca[j] * rs * coef[5 * Cp + k];
+      cp[j] = ca[j] * coef[4 * Cp + k] - cq[j] * mu;
     }
-    Vec16<E>::store(dx + off, o);
+    RowWalk w(r0 + rg, r1, RG, T);
+    while (w.valid()) {
+      size_t off[U];
+      bool ok[U];
+      float d[U][CH], xv[U][CH];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { ok[u] = w.valid(); off[u] = w.mem_row() * Cp + ch * CH; w.next(); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (ok[u]) { Vec16<E>::load(dy + off[u], d[u]); Vec16<E>::load(x + off[u], xv[u]); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int j = 0; j < CH; j += 2) {
+          const f32x2 xx = {xv[u][j], xv[u][j + 1]}, a2 = {ca[j], ca[j + 1]};
+          const f32x2 g = f32x2{d[u][j], d[u][j + 1]} * gelu_grad_pair<E>(fma2(a2, xx, f32x2{cb[j], cb[j + 1]}));
+          const f32x2 o = fma2(a2, g, -fma2(f32x2{cq[j], cq[j + 1]}, xx, f32x2{cp[j], cp[j + 1]}));
+          d[u][j] = o.x; d[u][j + 1] = o.y;
+        }
+        Vec16<E>::store(dx + off[u], d[u]);
+      }
+    }
   }
 }
 
@@ -535,61 +616,87 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restr
 // ------------------------------------------------------------------------------------------------
 template <typename E>
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const E* __restrict__ x, E* __restrict__ y, int B, int T, int Ch) {
-  constexpr int CH = Vec16<E>::N;
+  constexpr int CH = Vec16<E>::N, U = 2;
   const int nch = Ch / CH;
-  const size_t total = (size_t)B * T * nch;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ch = i % nch;
-    const size_t vr = i / nch;
-    const int b = vr / T, t = vr - (size_t)b * T;
-    const size_t row = (size_t)b * rows_tp(T) + PAD + t;
-    float a[CH], g[CH];
-    Vec16<E>::load(x + row * 2 * Ch + ch * CH, a);
-    Vec16<E>::load(x + row * 2 * Ch + Ch + ch * CH, g);
+  const int RG = nch >= 256 ? 1 : 256 / nch;
+  int r0, r1;
+  block_rows(B, T, r0, r1);
+  for (int c = threadIdx.x; c < RG * nch; c += 256) {
+    const int ch = c % nch, rg = c / nch;
+    RowWalk w(r0 + rg, r1, RG, T);
+    while (w.valid()) {
+      size_t row[U];
+      bool ok[U];
+      float a[U][CH], g[U][CH];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) a[j] *= sigmoid_f(g[j]);
-    Vec16<E>::store(y + row * Ch + ch * CH, a);
+      for (int u = 0; u < U; ++u) { ok[u] = w.valid(); row[u] = w.mem_row(); w.next(); }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[u]) {
+          Vec16<E>::load(x + row[u] * 2 * Ch + ch * CH, a[u]);
+          Vec16<E>::load(x + row[u] * 2 * Ch + Ch + ch * CH, g[u]);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) a[u][j] *= sigmoid_f(g[u][j]);
+        Vec16<E>::store(y + row[u] * Ch + ch * CH, a[u]);
+      }
+    }
   }
 }
 
 template <typename E>
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const E* __restrict__ x, const E* __restrict__ dy,
                                                       E* __restrict__ dx, int B, int T, int Ch) {
-  const int nch = Ch / 4;
-  const size_t total = (size_t)B * T * nch;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ch = i % nch;
-    const size_t vr = i / nch;
-    const int b = vr / T, t = vr - (size_t)b * T;
-    const size_t row = (size_t)b * rows_tp(T) + PAD + t;
-    const float4 a4 = load4(x + row * 2 * Ch + ch * 4), g4 = load4(x + row * 2 * Ch + Ch + ch * 4);
-    const float4 d4 = load4(dy + row * Ch + ch * 4);
-    const float a[4] = {a4.x, a4.y, a4.z, a4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w};
-    float da[4], dg[4];
+  constexpr int CH = Vec16<E>::N;
+  const int nch = Ch / CH;
+  const int RG = nch >= 256 ? 1 : 256 / nch;
+  int r0, r1;
+  block_rows(B, T, r0, r1);
+  for (int c = threadIdx.x; c < RG * nch; c += 256) {
+    const int ch = c % nch, rg = c / nch;
+    for (RowWalk w(r0 + rg, r1, RG, T); w.valid(); w.next()) {
+      const size_t row = w.mem_row();
+      float a[CH], g[CH], d[CH];
+      Vec16<E>::load(x + row * 2 * Ch + ch * CH, a);
+      Vec16<E>::load(x + row * 2 * Ch + Ch + ch * CH, g);
+      Vec16<E>::load(dy + row * Ch + ch * CH, d);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float s = sigmoid_f(g[j]);
-      da[j] = d[j] * s;
-      dg[j] = d[j] * a[j] * s * (1.f - s);
+      for (int j = 0; j < CH; ++j) {
+        const float sg = sigmoid_f(g[j]);
+        g[j] = d[j] * a[j] * sg * (1.f - sg);               // same expression order as bwd_colsum_kernel<1> (bit-equal outputs)
+        a[j] = d[j] * sg;
+      }
+      Vec16<E>::store(dx + row * 2 * Ch + ch * CH, a);
+      Vec16<E>::store(dx + row * 2 * Ch + Ch + ch * CH, g);
     }
-    store4(dx + row * 2 * Ch + ch * 4, make_float4(da[0], da[1], da[2], da[3]));
-    store4(dx + row * 2 * Ch + Ch + ch * 4, make_float4(dg[0], dg[1], dg[2], dg[3]));
   }
 }
 
 template <typename E>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const E* __restrict__ u, const E* __restrict__ dz,
                                                        E* __restrict__ du, int B, int T, int Cp) {
-  const int nch = Cp / 4;
-  const size_t total = (size_t)B * T * nch;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ch = i % nch;
-    const size_t vr = i / nch;
-    const int b = vr / T, t = vr - (size_t)b * T;
-    const size_t off = ((size_t)b * rows_tp(T) + PAD + t) * Cp + ch * 4;
-    const float4 uv = load4(u + off), d = load4(dz + off);
-    store4(du + off, make_float4(d.x * gelu_grad_f<E>(uv.x), d.y * gelu_grad_f<E>(uv.y), d.z * gelu_grad_f<E>(uv.z),
-                                 d.w * gelu_grad_f<E>(uv.w)));
+  constexpr int CH = Vec16<E>::N;
+  const int nch = Cp / CH;
+  const int RG = nch >= 256 ? 1 : 256 / nch;
+  int r0, r1;
+  block_rows(B, T, r0, r1);
+  for (int c = threadIdx.x; c < RG * nch; c += 256) {
+    const int ch = c % nch, rg = c / nch;
+    for (RowWalk w(r0 + rg, r1, RG, T); w.valid(); w.next()) {
+      const size_t off = w.mem_row() * Cp + ch * CH;
+      float uv[CH], d[CH];
+      Vec16<E>::load(u + off, uv);
+      Vec16<E>::load(dz + off, d);
+#pragma unroll
+      for (int j = 0; j < CH; j += 2) {
+        const f32x2 o = f32x2{d[j], d[j + 1]} * gelu_grad_pair<E>(f32x2{uv[j], uv[j + 1]});
+        d[j] = o.x; d[j + 1] = o.y;
+      }
+      Vec16<E>::store(du + off, d);
+    }
   }
 }
 
@@ -779,8 +886,7 @@ extern "C" int sda_bn_finalize(const float* partial, int ntiles, double count, c
 extern "C" int sda_bn_gelu_forward(const void* x, void* y, const float* scale, const float* shift, int B, int T,
                                    int Cp, int dtype, void* stream) {
   if (!x || !y || !scale || !shift || Cp % 64) { set_error("bn_gelu_forward: bad arguments"); return -1; }
-  const size_t total = (size_t)B * T * (Cp / 4);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_fwd_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_fwd_kernel<E>, dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, (hipStream_t)stream,
                                          (const E*)x, (E*)y, scale, shift, B, T, Cp));
   return check_launch("bn_gelu_forward");
 }
@@ -816,12 +922,11 @@ extern "C" int sda_bn_gelu_backward_apply(const void* dy, const void* x, const f
   if (!dy || !x || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !coef || !dx || Cp % 64 || count < 1.0) {
     set_error("bn_gelu_backward_apply: bad arguments"); return -1;
   }
-  const size_t total = (size_t)B * T * (Cp / 4);
   const float inv_count = (float)(1.0 / count);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((Cp + 255) / 256), dim3(256), 0, st, mean, rstd, gamma, beta, C, dbeta,
                      dgamma, inv_count, coef, Cp);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, st,
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, st,
                                          (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
   return check_launch("bn_gelu_backward_apply");
 }
@@ -834,11 +939,10 @@ extern "C" int sda_bn_gelu_backward_from_stats(const float* partial, int nrows, 
       Cp % 64 || count < 1.0) {
     set_error("bn_gelu_backward_from_stats: bad arguments"); return -1;
   }
-  const size_t total = (size_t)B * T * (Cp / 4);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_stats_coef_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, partial, nrows, mean, rstd, gamma, beta, C,
                      (float)(1.0 / count), dbeta, dgamma, coef, Cp);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, st,
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, st,
                                          (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
   return check_launch("bn_gelu_backward_from_stats");
 }
@@ -859,24 +963,21 @@ extern "C" int sda_reduce_scratch_floats(int Cp) { return RED_MAX_BLOCKS * 2 * C
 
 extern "C" int sda_glu_forward(const void* x, void* y, int B, int T, int Ch, int dtype, void* stream) {
   if (!x || !y || Ch % 64) { set_error("glu_forward: bad arguments"); return -1; }
-  const size_t total = (size_t)B * T * (Ch / 4);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(glu_fwd_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(glu_fwd_kernel<E>, dim3(stream_blocks(B, T, Ch / Vec16<E>::N)), dim3(256), 0, (hipStream_t)stream,
                                          (const E*)x, (E*)y, B, T, Ch));
   return check_launch("glu_forward");
 }
 
 extern "C" int sda_glu_backward(const void* x, const void* dy, void* dx, int B, int T, int Ch, int dtype, void* stream) {
   if (!x || !dy || !dx || Ch % 64) { set_error("glu_backward: bad arguments"); return -1; }
-  const size_t total = (size_t)B * T * (Ch / 4);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(glu_bwd_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(glu_bwd_kernel<E>, dim3(stream_blocks(B, T, Ch / Vec16<E>::N)), dim3(256), 0, (hipStream_t)stream,
                                          (const E*)x, (const E*)dy, (E*)dx, B, T, Ch));
   return check_launch("glu_backward");
 }
 
 extern "C" int sda_gelu_backward(const void* u, const void* dz, void* du, int B, int T, int Cp, int dtype, void* stream) {
   if (!u || !dz || !du || Cp % 64) { set_error("gelu_backward: bad arguments"); return -1; }
-  const size_t total = (size_t)B * T * (Cp / 4);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(gelu_bwd_kernel<E>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(gelu_bwd_kernel<E>, dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, (hipStream_t)stream,
                                          (const E*)u, (const E*)dz, (E*)du, B, T, Cp));
   return check_launch("gelu_backward");
 }
@@ -891,6 +992,18 @@ extern "C" int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, 
                                          (const E*)dy, (E*)dx, scratch, B, T, Ch));
   hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
   return check_launch("glu_backward_colsum");
+}
+
+extern "C" int sda_glu_backward_colsum_og(const void* out, const void* gate, const void* dy, void* dx, float* colsum,
+                                          float* scratch, int B, int T, int Ch, int dtype, void* stream) {
+  if (!out || !gate || !dy || !dx || !colsum || !scratch || Ch % 64 || Ch > 1024) { set_error("glu_backward_colsum_og: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = red_blocks(B, T);
+  const size_t lds = (size_t)(256 / (Ch / (dtype == SDA_F32 ? 4 : 8))) * 2 * Ch * sizeof(float);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 2>), dim3(nb), dim3(256), lds, st, (const E*)out,
+                                         (const E*)dy, (E*)dx, scratch, B, T, Ch, (const E*)gate));
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
+  return check_launch("glu_backward_colsum_og");
 }
 
 extern "C" int sda_gelu_backward_colsum(const void* u, const void* dz, void* du, float* colsum, float* scratch, int B, int T,

@@ -176,19 +176,40 @@ template <> __device__ inline f32x4 mma16<float>(const uint4& a, const uint4& b,
 }
 
 // GELU (erf form, F.gelu default — models.py:158,161,194,195) and its derivative, by storage type.
-// fp32 storage: libm erff, the exact path.  bf16 storage: the normal CDF by Abramowitz-Stegun 7.1.26
-// (|error| <= 1.5e-7 absolute, 2^-9 is the storage resolution) — one v_rcp + one v_exp shared by the CDF and
-// the density, about a third of erff's instructions; the GELU kernels of the bf16 path are VALU-bound on erff.
-__device__ inline void normal_cdf_pdf(float x, float& cdf, float& pdf) {
-  const float e = __expf(-0.5f * x * x);                           // exp(-z^2), z = |x| / sqrt(2)
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float tail = 0.5f * p * t * e;                             // 0.5 * erfc(z)
-  cdf = x >= 0.f ? 1.0f - tail : tail;
-  pdf = 0.3989422804014327f * e;
+// fp32 storage: libm erff, the exact path.  16-bit storage: the normal tail 0.5*erfc(|x|/sqrt2) by Abramowitz-Stegun
+// 26.2.17 (|error| <= 7.5e-8 absolute; 2^-9 / 2^-11 is the storage resolution) — one v_rcp + one v_exp shared by the
+// CDF and the density.  The passes that apply it are VALU-bound, not HBM-bound, unless it stays under ~13 issue slots
+// per element (measured: affine only 19.7 us, this form written per element 26.6 us for 118 MB), so it is written on
+// PAIRS of elements: every multiply/add is a v_pk_*_f32 (two lanes of work per issue slot), and
+// GELU = max(x,0) - |x|*tail needs no compare/select.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ inline f32x2 splat2(float v) { return f32x2{v, v}; }
+// tail = 0.5*erfc(|x|/sqrt2) = 1 - Phi(|x|),  e = exp(-x^2/2)
+__device__ inline void normal_tail2(f32x2 x, f32x2& tail, f32x2& e) {
+  const f32x2 y = x * 0.849321800288f;                                // sqrt(log2(e)/2): exp(-x^2/2) = 2^-(y*y)
+  const f32x2 yy = y * y;
+  e = f32x2{__builtin_amdgcn_exp2f(-yy.x), __builtin_amdgcn_exp2f(-yy.y)};
+  const f32x2 t = {__builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x.x), 0.2316419f, 1.0f)),
+                   __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x.y), 0.2316419f, 1.0f))};
+  f32x2 q = fma2(t, splat2(0.5f * 1.061405429f), splat2(0.5f * -1.453152027f));   // 26.2.17's b5..b1 = 7.1.26's a5..a1 halved
+  q = fma2(q, t, splat2(0.5f * 1.421413741f));
+  q = fma2(q, t, splat2(0.5f * -0.284496736f));
+  q = fma2(q, t, splat2(0.5f * 0.254829592f));
+  tail = (q * t) * e;
+}
+__device__ inline f32x2 gelu2(f32x2 x) {                              // x*Phi(x) = max(x,0) - |x|*tail
+  f32x2 tail, e;
+  normal_tail2(x, tail, e);
+  return f32x2{__builtin_fmaf(-__builtin_fabsf(x.x), tail.x, __builtin_fmaxf(x.x, 0.f)),
+               __builtin_fmaf(-__builtin_fabsf(x.y), tail.y, __builtin_fmaxf(x.y, 0.f))};
+}
+__device__ inline f32x2 gelu_grad2(f32x2 x) {                         // Phi(x) + x*phi(x)
+  f32x2 tail, e;
+  normal_tail2(x, tail, e);
+  const f32x2 h = splat2(0.5f) - tail;                                // Phi(x) = 0.5 + sign(x)*(0.5 - tail)
+  const f32x2 cdf = f32x2{__builtin_copysignf(h.x, x.x), __builtin_copysignf(h.y, x.y)} + splat2(0.5f);
+  return fma2(x * 0.3989422804014327f, e, cdf);
 }
 template <typename E> __device__ inline float gelu_f(float x);
 template <typename E> __device__ inline float gelu_grad_f(float x);
@@ -198,21 +219,18 @@ template <> __device__ inline float gelu_grad_f<float>(float x) {
   const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
-template <> __device__ inline float gelu_f<uint16_t>(float x) {
-  float cdf, pdf;
-  normal_cdf_pdf(x, cdf, pdf);
-  return x * cdf;
-}
-template <> __device__ inline float gelu_grad_f<uint16_t>(float x) {
-  float cdf, pdf;
-  normal_cdf_pdf(x, cdf, pdf);
-  return fmaf(x, pdf, cdf);
-}
-// fp16 storage: the same shared-exp form (its 1.5e-7 absolute error is below half an fp16 ulp for |GELU| > 3e-4 and
-// below the smallest normal fp16 step elsewhere)
+template <> __device__ inline float gelu_f<uint16_t>(float x) { return gelu2(splat2(x)).x; }
+template <> __device__ inline float gelu_grad_f<uint16_t>(float x) { return gelu_grad2(splat2(x)).x; }
+// fp16 storage: the same form (its absolute error is below half an fp16 ulp for |GELU| > 3e-4 and below the smallest
+// normal fp16 step elsewhere)
 template <> __device__ inline float gelu_f<half_t>(float x) { return gelu_f<uint16_t>(x); }
 template <> __device__ inline float gelu_grad_f<half_t>(float x) { return gelu_grad_f<uint16_t>(x); }
-__device__ inline float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// element pairs (the elementwise passes): 16-bit storage on the packed form, fp32 storage per element on erff
+template <typename E> __device__ inline f32x2 gelu_pair(f32x2 x) { return gelu2(x); }
+template <typename E> __device__ inline f32x2 gelu_grad_pair(f32x2 x) { return gelu_grad2(x); }
+template <> __device__ inline f32x2 gelu_pair<float>(f32x2 x) { return f32x2{gelu_f<float>(x.x), gelu_f<float>(x.y)}; }
+template <> __device__ inline f32x2 gelu_grad_pair<float>(f32x2 x) { return f32x2{gelu_grad_f<float>(x.x), gelu_grad_f<float>(x.y)}; }
+__device__ inline float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // v_rcp_f32: 1 ulp
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll

@@ -63,6 +63,7 @@ class EncoderCtx:
     W_sa: Optional[torch.Tensor] = None
     packed_T: Dict[str, torch.Tensor] = field(default_factory=dict)
     packed_T_ready: Optional[torch.cuda.Event] = None     # side-stream packing of packed_T has finished
+    glu_fused: bool = False                               # F.glu ran in conv2's epilogue: bufs hold the gate, not [value | gate]
 
 
 class EncoderEngine:
@@ -84,10 +85,12 @@ class EncoderEngine:
         # weight-gradient chains (wgrad_gemm -> reduce_slabs -> unpack) depend only on dy and a saved
         # activation, never on each other or on the data-gradient chain: run them on a second HIP stream
         self.wgrad_side_stream = True
+        self.side_stream_priority = 0        # HIP stream priority of the weight-gradient / packing stream
         self.pack_on_side_stream = True      # per-step operand packing runs beside the first layers, not in front
         self.forward_pair_tiles = True       # forward k = 3 convs (nothing competes for the CU's LDS there): two
                                              # tiles per workgroup share each weight slab — fewer LDS-DMA bytes per FLOP
         self.flat_tiles_forward = True       # k = 3 convs on the 256-row flat-tile kernel (conv3_flat.hip) where it applies
+        self.fuse_glu_forward = True         # F.glu in conv2's epilogue (flat-tile kernel, D2p % 80 == 0): no [value | gate] buffer
         # backward keeps the 128-row tile kernel (40 KB of LDS per workgroup): the flat kernel's two 76 KB workgroups fill a
         # CU's LDS, the weight-gradient GEMMs of the side stream then wait for the conv instead of running beside it
         # (measured in the step: +2 %; with one flat workgroup per CU: +7 %)
@@ -148,14 +151,19 @@ class EncoderEngine:
         perm, seg = self._seg_cache[key]
         return perm, seg, nseg
 
+    @property
+    def glu_fused(self) -> bool:
+        return bool(self.fuse_glu_forward and self.flat_tiles_forward and self.d.D2p % 80 == 0)
+
     # ------------------------------------------------------------------ operand packing plans
     def _plans(self, P, dev):
-        key = (str(dev), self.dtype)
+        key = (str(dev), self.dtype, self.glu_fused)
         if getattr(self, "_plan_key", None) == key:
             return self._fwd_plan, self._bwd_plan
         d = self.d
         f, b = ops.PackPlan(self.dtype, dev), ops.PackPlan(self.dtype, dev)
         glu = dict(glu_half=d.D2, glu_half_p=d.D2p)
+        glu_fwd = dict(glu, glu_tile=80) if self.glu_fused else glu      # SDA_EPI_GLU's 80 value + 80 gate channels per tile
         f.add_weight("sb_w", P["sb_w"], d.D1p, d.D1p)
         f.add_vector("sb_b", P["sb_b"], d.D1p)
         f.add_weight("subj_w", P["subj_w"], d.D1p, d.D1p)
@@ -168,8 +176,8 @@ class EncoderEngine:
                 f.add_weight(f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p)
                 f.add_vector(f"b{k}.c{j}b", P[f"b{k}.c{j}b"], d.D2p)
                 b.add_weight(f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p, mode=1)
-            f.add_weight(f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, **glu)
-            f.add_vector(f"b{k}.c2b", P[f"b{k}.c2b"], 2 * d.D2p, **glu)
+            f.add_weight(f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, **glu_fwd)
+            f.add_vector(f"b{k}.c2b", P[f"b{k}.c2b"], 2 * d.D2p, **glu_fwd)
             b.add_weight(f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, mode=1, **glu)
         f.add_weight("f1w", P["f1w"], d.F1p, d.D2p)
         f.add_vector("f1b", P["f1b"], d.F1p)
@@ -192,6 +200,7 @@ class EncoderEngine:
             self._gen += 1
         self._touch_shape(space, B, T)
         ctx = EncoderCtx(B=B, T=T, gen=self._gen, training=training)
+        ctx.glu_fused = self.glu_fused
         bufs, pk = ctx.bufs, ctx.packed
 
         def rows(name, Cp):
@@ -231,7 +240,7 @@ class EncoderEngine:
         if self.pack_on_side_stream:
             side = self._side.get(str(dev))
             if side is None:
-                side = self._side[str(dev)] = torch.cuda.Stream(device=dev)
+                side = self._side[str(dev)] = torch.cuda.Stream(device=dev, priority=self.side_stream_priority)
             ev = torch.cuda.Event()
             ev.record(main)                      # the optimiser's update of P is on the main stream
             side.wait_event(ev)
@@ -303,10 +312,16 @@ class EncoderEngine:
                 bufs[f"b{k}.h{j}"], bufs[f"b{k}.a{j}"] = h, a
                 x = a
             w, bias = pk[f"b{k}.c2w"], pk[f"b{k}.c2b"]
-            c2 = ops.conv_gemm(x, w, rows(f"b{k}.c2", 2 * d.D2p), B=B, T=T, KS=3, dil=dil[2], bias=bias, alg_dims=(d.D2, 2 * d.D2),
-                               flags=k3_flags)
-            x = ops.glu_forward(c2, rows(f"x{k + 1}", d.D2p), B, T)
-            bufs[f"b{k}.c2"], bufs[f"x{k + 1}"] = c2, x
+            if ctx.glu_fused:        # F.glu in the conv's epilogue: only the product and (for backward) the gate are stored
+                gate = rows(f"b{k}.g", d.D2p) if need_grad else None
+                x = ops.conv_gemm(x, w, rows(f"x{k + 1}", d.D2p), B=B, T=T, KS=3, dil=dil[2], bias=bias, y_pre=gate,
+                                  alg_dims=(d.D2, 2 * d.D2), flags=k3_flags | L.EPI_GLU)
+                bufs[f"b{k}.g"], bufs[f"x{k + 1}"] = gate, x
+            else:
+                c2 = ops.conv_gemm(x, w, rows(f"b{k}.c2", 2 * d.D2p), B=B, T=T, KS=3, dil=dil[2], bias=bias,
+                                   alg_dims=(d.D2, 2 * d.D2), flags=k3_flags)
+                x = ops.glu_forward(c2, rows(f"x{k + 1}", d.D2p), B, T)
+                bufs[f"b{k}.c2"], bufs[f"x{k + 1}"] = c2, x
 
         # ---- two 1x1 projections with GELU (models.py:194-195)
         u1, g1 = rows("u1", d.F1p), rows("g1", d.F1p)
@@ -376,7 +391,7 @@ class EncoderEngine:
         if self.wgrad_side_stream:
             side = self._side.get(str(dev))
             if side is None:
-                side = self._side[str(dev)] = torch.cuda.Stream(device=dev)
+                side = self._side[str(dev)] = torch.cuda.Stream(device=dev, priority=self.side_stream_priority)
 
         def on_side(fn):
             """Run `fn` (launches + allocations) on the side stream once everything queued on the main stream
@@ -452,7 +467,10 @@ class EncoderEngine:
             dil = block_dilations(k)
             glu = dict(glu_half=d.D2, glu_half_p=d.D2p)
             dc2 = tmp(f"dc2.{k}", 2 * d.D2p)          # per-layer buffers: a side-stream wgrad may still read them
-            cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
+            if ctx.glu_fused:
+                cs = ops.glu_backward_colsum_og(bufs[f"x{k + 1}"], bufs[f"b{k}.g"], dx, dc2, B, T, scratch)
+            else:
+                cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
             grads[f"b{k}.c2b"] = bias_grad(cs, 2 * d.D2, **glu)
             da1, tstats = dgrad(dc2, f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2],
                                 bn=(bufs[f"b{k}.h1"], ctx.bn[f"b{k}.bn1"][2]), **glu)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsdamd.so")
 F32, BF16, F16 = 0, 1, 2
 ROW_PAD = 16
 CH_ALIGN = 64
-EPI_GELU = 1
+EPI_GELU, EPI_GLU = 1, 2
 CONV_SINGLE_TILE, CONV_PAIR_TILES, CONV_FLAT_TILES, CONV_ONE_PER_CU = 4096, 8192, 16384, 32768
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
@@ -38,7 +38,7 @@ class WgradArgs(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("nW", i32), ("Cout", i32), ("Cin", i32), ("KS", i32), ("Cout_p", i32),
-                ("Cin_p", i32), ("mode", i32), ("glu_half", i32), ("glu_half_p", i32), ("is_vector", i32), ("total", i64)]
+                ("Cin_p", i32), ("mode", i32), ("glu_half", i32), ("glu_half_p", i32), ("is_vector", i32), ("glu_tile", i32), ("total", i64)]
 
 
 class AdamDesc(C.Structure):
@@ -78,6 +78,7 @@ SIGNATURES = {
     "sda_glu_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_gelu_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_glu_backward_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_glu_backward_colsum_og": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_gelu_backward_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_colsum": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_wgrad_gemm": (i32, [C.POINTER(WgradArgs), vp]),

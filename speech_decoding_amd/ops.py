@@ -183,21 +183,22 @@ class PackPlan:
         self._table = None
         self._sig = None
 
-    def add_weight(self, key, w, Cout_p, Cin_p, mode=0, glu_half=0, glu_half_p=0):
+    def add_weight(self, key, w, Cout_p, Cin_p, mode=0, glu_half=0, glu_half_p=0, glu_tile=0):
         if w.dim() == 3:
             w = w.unsqueeze(0)
         nW, Cout, Cin, KS = w.shape
         rows, cols = (Cout_p, Cin_p) if mode == 0 else (Cin_p, Cout_p)
         dst = torch.empty((nW, KS, rows, cols), dtype=self.dtype, device=self.device)
         self.items.append((key, w, dst, dict(nW=nW, Cout=Cout, Cin=Cin, KS=KS, Cout_p=Cout_p, Cin_p=Cin_p, mode=mode,
-                                             glu_half=glu_half, glu_half_p=glu_half_p, is_vector=0, total=dst.numel())))
+                                             glu_half=glu_half, glu_half_p=glu_half_p, glu_tile=glu_tile, is_vector=0,
+                                             total=dst.numel())))
         self.out[key] = dst
         return dst
 
-    def add_vector(self, key, v, Cp, glu_half=0, glu_half_p=0):
+    def add_vector(self, key, v, Cp, glu_half=0, glu_half_p=0, glu_tile=0):
         dst = torch.empty(Cp, dtype=torch.float32, device=self.device)
         self.items.append((key, v, dst, dict(nW=1, Cout=v.numel(), Cin=1, KS=1, Cout_p=Cp, Cin_p=1, mode=0,
-                                             glu_half=glu_half, glu_half_p=glu_half_p, is_vector=1, total=Cp)))
+                                             glu_half=glu_half, glu_half_p=glu_half_p, glu_tile=glu_tile, is_vector=1, total=Cp)))
         self.out[key] = dst
         return dst
 
@@ -281,16 +282,20 @@ def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=N
     a.x, a.w, a.bias, a.res, a.y, a.y_pre = _p(x), _p(w), _p(bias), _p(res), _p(y), _p(y_pre)
     a.widx, a.stats, a.partial = _p(widx), _p(stats), None
     a.bn_x, a.bn_coef = _p(bn_x), _p(bn_coef)
-    a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = B, T, x.shape[1], y.shape[1], KS, dil
+    glu = bool(flags & L.EPI_GLU)        # y (and y_pre = the gate) are half as wide as the conv's output channels
+    Cout_p = 2 * y.shape[1] if glu else y.shape[1]
+    a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = B, T, x.shape[1], Cout_p, KS, dil
+    if glu and (res is not None or stats is not None or bn_x is not None or (y_pre is not None and y_pre.shape != y.shape)):
+        raise L.SdaError("conv_gemm: EPI_GLU takes no residual / statistics and a gate buffer of y's shape")
     if bn_x is not None and (bn_x.shape != y.shape or bn_coef is None or bn_coef.numel() != 4 * y.shape[1] or stats is None):
         raise L.SdaError("conv_gemm: bn_x needs the shape of y, a [4][Cout_p] coefficient table and a stats buffer")
-    if w.shape[-1] != x.shape[1] or w.shape[-2] != y.shape[1] or w.shape[-3] != KS:
+    if w.shape[-1] != x.shape[1] or w.shape[-2] != Cout_p or w.shape[-3] != KS:
         raise L.SdaError(f"conv_gemm: weight {tuple(w.shape)} does not match x {tuple(x.shape)} / y {tuple(y.shape)}")
     a.x_pitch, a.w_pitch = x.shape[1], w.shape[-1]
     a.x_row0, a.x_sample_rows, a.x_rows_limit = L.ROW_PAD, L.rows_tp(T), x.shape[0]
     if x.shape[0] < L.rows_alloc(B, T) or y.shape[0] < L.rows_alloc(B, T):
         raise L.SdaError("conv_gemm: RL buffers too small for (B, T)")
-    a.w_rows_limit, a.ksplit = y.shape[1], 1
+    a.w_rows_limit, a.ksplit = Cout_p, 1
     a.flags, a.dtype = (L.EPI_GELU if gelu else 0) | flags, dt_code(x.dtype)
     if TIMER is not None and "conv_gemm" in TIMER.families:
         cin, cout = alg_dims if alg_dims is not None else (x.shape[1], y.shape[1])
@@ -298,7 +303,7 @@ def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=N
         e0.record()
         L.check(L.load().sda_conv_gemm(C.byref(a), _st()), "conv_gemm")
         e1.record()
-        TIMER.records.append((("conv_gemm", str(x.dtype).replace("torch.", ""), conv_tile_co(y.shape[1]), KS),
+        TIMER.records.append((("conv_gemm", str(x.dtype).replace("torch.", ""), conv_tile_co(Cout_p), KS),
                               2.0 * B * T * KS * cin * cout, e0, e1))
         return y
     L.check(L.load().sda_conv_gemm(C.byref(a), _st()), "conv_gemm")
@@ -411,6 +416,15 @@ def glu_backward_colsum(x, dy, dx, B, T, scratch):
     cs = torch.empty(2 * dy.shape[1], dtype=torch.float32, device=x.device)
     L.check(L.load().sda_glu_backward_colsum(_p(x), _p(dy), _p(dx), _p(cs), _p(scratch), B, T, dy.shape[1], dt_code(x.dtype), _st()),
             "glu_backward_colsum")
+    return cs
+
+
+def glu_backward_colsum_og(out, gate, dy, dx, B, T, scratch):
+    """GLU backward after a fused forward (conv_gemm(flags=EPI_GLU)): `out` = value * sigmoid(gate) and `gate` instead of the
+    [value | gate] buffer; same dx ([d value | d gate]) and column sums as glu_backward_colsum."""
+    cs = torch.empty(2 * dy.shape[1], dtype=torch.float32, device=dy.device)
+    L.check(L.load().sda_glu_backward_colsum_og(_p(out), _p(gate), _p(dy), _p(dx), _p(cs), _p(scratch), B, T, dy.shape[1],
+                                                dt_code(dy.dtype), _st()), "glu_backward_colsum_og")
     return cs
 
 

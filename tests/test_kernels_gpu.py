@@ -110,6 +110,57 @@ def test_conv3_forward_bias_residual_stats(ops, dtype, cin, cout, dil, T, tiling
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,half,dil,T,B", [(320, 320, 4, 360, 5), (64, 300, 2, 129, 3), (96, 600, 16, 200, 2)])
+def test_conv3_glu_epilogue_equals_conv_then_glu(ops, dtype, cin, half, dil, T, B):
+    """F.glu in the conv's epilogue (EPI_GLU, weights packed 80 values + 80 gates per tile) is BIT-equal to the conv
+    followed by glu_forward; the gate it keeps is the conv's gate half; the (out, gate) backward matches the [a | g] one."""
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(cin + half + dil)
+    x = q(torch.randn(B, cin, T, generator=g), dtype)
+    w = q(torch.randn(2 * half, cin, 3, generator=g) / math.sqrt(3 * cin), dtype)
+    bias = torch.randn(2 * half, generator=g)
+    Cin_p, Hp = L.pad_channels(cin), L.pad_channels(half)
+    assert Hp % 80 == 0
+    xb = to_rows(ops, x, dtype)
+    w_d, b_d = w.to(DEV), bias.to(DEV)
+    packs = {}
+    for name, tile in (("halves", 0), ("tiles", 80)):
+        plan = ops.PackPlan(dtype, DEV)
+        plan.add_weight("w", w_d, 2 * Hp, Cin_p, glu_half=half, glu_half_p=Hp, glu_tile=tile)
+        plan.add_vector("b", b_d, 2 * Hp, glu_half=half, glu_half_p=Hp, glu_tile=tile)
+        packs[name] = dict(plan.run({"w": w_d, "b": b_d}))
+    flat = L.CONV_FLAT_TILES
+    c2 = ops.conv_gemm(xb, packs["halves"]["w"], ops.new_rows(B, T, 2 * Hp, dtype, DEV), B=B, T=T, KS=3, dil=dil,
+                       bias=packs["halves"]["b"], flags=flat)
+    out_ref = ops.glu_forward(c2, ops.new_rows(B, T, Hp, dtype, DEV), B, T)
+    out, gate = ops.new_rows(B, T, Hp, dtype, DEV), ops.new_rows(B, T, Hp, dtype, DEV)
+    ops.conv_gemm(xb, packs["tiles"]["w"], out, B=B, T=T, KS=3, dil=dil, bias=packs["tiles"]["b"], y_pre=gate,
+                  flags=flat | L.EPI_GLU)
+    assert torch.equal(out, out_ref)
+    assert torch.equal(gate, c2[:, Hp:].contiguous())
+    ref = TF.glu(TF.conv1d(x, w, bias, padding=dil, dilation=dil), dim=1)
+    np.testing.assert_allclose(from_rows(ops, out, B, half, T).numpy(), ref.numpy(), **tol(dtype, 3 * cin))
+    # without a gate buffer (inference)
+    out2 = ops.new_rows(B, T, Hp, dtype, DEV)
+    ops.conv_gemm(xb, packs["tiles"]["w"], out2, B=B, T=T, KS=3, dil=dil, bias=packs["tiles"]["b"], flags=flat | L.EPI_GLU)
+    assert torch.equal(out2, out)
+    # backward from (out, gate) against the [value | gate] form
+    dy = to_rows(ops, q(torch.randn(B, half, T, generator=g), dtype), dtype)
+    scratch = ops.reduce_scratch(2 * Hp, DEV)
+    dx_ref, dx = ops.new_rows(B, T, 2 * Hp, dtype, DEV), ops.new_rows(B, T, 2 * Hp, dtype, DEV)
+    cs_ref = ops.glu_backward_colsum(c2, dy, dx_ref, B, T, scratch)
+    cs = ops.glu_backward_colsum_og(out, gate, dy, dx, B, T, scratch)
+    assert torch.equal(dx[:, :Hp], dx_ref[:, :Hp])                      # d value = dy * sigmoid(gate): same expression
+    t = tol(dtype, 4)
+    np.testing.assert_allclose(dx[:, Hp:].float().cpu().numpy(), dx_ref[:, Hp:].float().cpu().numpy(), **t)
+    ts = tol(dtype, B * T)
+    np.testing.assert_allclose(cs.cpu().numpy(), cs_ref.cpu().numpy(), rtol=ts["rtol"], atol=ts["atol"])
+    # EPI_GLU is refused where the flat-tile kernel does not apply
+    with pytest.raises(L.SdaError):
+        ops.conv_gemm(xb, packs["tiles"]["w"], out2, B=B, T=T, KS=3, dil=dil, bias=packs["tiles"]["b"], flags=L.EPI_GLU)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv1_per_sample_weights_and_gelu(ops, dtype):
     from speech_decoding_amd import lib as L
     g = torch.Generator().manual_seed(3)

@@ -48,18 +48,25 @@ for spec in specs:
     variants[name] = {kv.split("=")[0]: eval(kv.split("=")[1]) for kv in rest.split(",") if kv}
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 eng = enc.engine
+eng.main_priority = 0
 defaults = {k: getattr(eng, k) for v in variants.values() for k in v}
+eng.main_priority = 0                   # pseudo-attribute of this tool: priority of the stream the step is issued on
+streams = {0: torch.cuda.current_stream(dev), -1: torch.cuda.Stream(device=dev, priority=-1)}
 def apply(v):
     for k, d in defaults.items(): setattr(eng, k, d)
     for k, x in v.items(): setattr(eng, k, x)
     eng._seg_cache.clear()
+    eng._side.clear()
 res = {k: [] for k in variants}
 for k, v in variants.items():           # warm-up of every variant (workspaces, attribute calls)
     apply(v)
-    for _ in range(3): step()
+    with torch.cuda.stream(streams[eng.main_priority]):
+        for _ in range(3): step()
+    torch.cuda.synchronize()
 for r in range(rounds):
     for k, v in variants.items():
         apply(v)
-        res[k].append(timed())
+        with torch.cuda.stream(streams[eng.main_priority]):
+            res[k].append(timed())
 for k, v in res.items():
     print(f"{k:10s} median {np.median(v):.3f} ms  min {min(v):.3f}  all {[round(x, 3) for x in v]}")
