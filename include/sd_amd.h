@@ -130,7 +130,9 @@ typedef struct sda_conv_args {
                          * dg = y * GELU'(gamma * xhat + beta), xhat = (bn_x - mean) * rstd, y as stored */
   const float* bn_coef; /* with bn_x: [4][Cout_p] = gamma, beta, mean, rstd (zero on padded channels) */
   int B, T, Cin_p, Cout_p, KS, dil;
-  long x_pitch, w_pitch; /* elements per row of x / per output-channel row of w */
+  long x_pitch, w_pitch; /* elements per row of x / per output-channel row of w.  With KS == 1, x_pitch < Cin_p is allowed:
+                          * rows then overlap — a frame-major buffer read with pitch stride*C and row length k*C is the
+                          * im2col matrix of a strided Conv1d (the wav2vec2 feature encoder) */
   long x_row0;           /* first row of sample 0 (SDA_ROW_PAD for RL, 0 for plain matrices) */
   long x_sample_rows;    /* rows between consecutive samples (T + SDA_ROW_PAD for RL) */
   long x_rows_limit;     /* rows >= limit read as zero */
@@ -275,6 +277,34 @@ int sda_collate_rows(const float* src, float* dst, long rows, int T, int baselin
  * window, win_cstride[b] is that session's channel stride in elements (device arrays of length B). dst (B, C, T). */
 int sda_collate_windows(const float* const* win_ptr, const long* win_cstride, float* dst, int B, int C, int T,
                         int baseline_len, float clamp_lim, int clamp, void* stream);
+
+/* ---- Frozen wav2vec 2.0 speech embedder (utils/wav2vec_util.py:14-32 calls the third-party HF Wav2Vec2Model; this is that
+ * model's published forward for the layer-norm / stable-layer-norm variant xlsr-53 uses).  Every Linear, strided Conv1d and
+ * the grouped positional conv run on sda_conv_gemm (kernel size 1 on overlapping-row views); these are the other stages.
+ * Activations are row-layout buffers of ONE chunk: row SDA_ROW_PAD + t = frame t. ---- */
+/* Feature-encoder layer 0: y = GELU(LayerNorm_C(Conv1d(1 -> C, K, stride)(wave) + bias)); wave fp32 [n_samples] on the
+ * device, w fp32 [C][K], T = (n_samples - K) / stride + 1 frames */
+int sda_w2v_conv0(const float* wave, long n_samples, const float* w, const float* bias, const float* gamma,
+                  const float* beta, void* y, int T, int C, int Cp, int K, int stride, float eps, int dtype, void* stream);
+/* y = LayerNorm over the C valid channels of each of T rows (biased variance, eps inside the root), affine, then GELU
+ * when `gelu`; pad channels of y are written as zero.  Cp * sizeof(element) <= 4096 */
+int sda_layernorm_rows(const void* x, void* y, const float* gamma, const float* beta, int T, int C, int Cp, float eps,
+                       int gelu, int dtype, void* stream);
+/* Grouped positional conv, input side: channels [g*gw, (g+1)*gw) of frame t -> xg[g][lead + t][0..gw) (G buffers of
+ * group_rows rows x gwp channels; rows outside [lead, lead + T) and channels >= gw must already be zero) */
+int sda_w2v_group_split(const void* h, void* xg, int T, int Hp, int gw, int gwp, int G, long group_rows, int lead,
+                        int dtype, void* stream);
+/* ... output side: out[t][g*gw + c] = h[t][g*gw + c] + yg[g][SDA_ROW_PAD + t][c] */
+int sda_w2v_group_merge_add(const void* h, const void* yg, void* out, int T, int Hp, int gw, int gwp, int G, long yg_rows,
+                            int dtype, void* stream);
+/* out = softmax(q k^T * scale) v per head (no mask): q, k row layout with pitch qk_pitch, head h in columns
+ * [64h, 64h+64); vt = V transposed, plain matrix [heads*64][vt_pitch >= T rounded up to 64] (columns >= T finite);
+ * out row layout with pitch out_pitch.  head_dim must be 64 */
+int sda_w2v_attention(const void* q, const void* k, const void* vt, void* out, int T, int heads, int head_dim,
+                      long qk_pitch, long vt_pitch, long out_pitch, float scale, int dtype, void* stream);
+/* out fp32 dense [T][C] = mean of four row-layout hidden states (wav2vec_util.py:18-20) */
+int sda_w2v_mean4(const void* a, const void* b, const void* c, const void* d, float* out, int T, int C, int Cp,
+                  int dtype, void* stream);
 
 #ifdef __cplusplus
 }

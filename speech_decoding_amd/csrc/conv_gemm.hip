@@ -487,7 +487,10 @@ extern "C" int sda_conv_gemm(const sda_conv_args* a, void* stream) {
   if (a->KS != 1 && a->KS != 3) { set_error("conv_gemm: kernel size %d not supported (1 or 3)", a->KS); return -1; }
   if (a->dil < 0 || a->dil > PAD) { set_error("conv_gemm: dilation %d outside [0, %d]", a->dil, PAD); return -1; }
   if (a->Cout_p % 64 || a->Cin_p % 64) { set_error("conv_gemm: channel extents (%d, %d) must be multiples of 64", a->Cin_p, a->Cout_p); return -1; }
-  if (a->x_pitch % 8 || a->w_pitch % 8 || a->x_pitch < a->Cin_p || a->w_pitch < a->Cin_p) { set_error("conv_gemm: bad pitch"); return -1; }
+  // (x_pitch < Cin_p is allowed for kernel size 1: overlapping rows = the im2col view of a strided convolution)
+  if (a->x_pitch % 8 || a->w_pitch % 8 || a->x_pitch < 8 || (a->x_pitch < a->Cin_p && a->KS != 1) || a->w_pitch < a->Cin_p) {
+    set_error("conv_gemm: bad pitch"); return -1;
+  }
   if (a->ksplit < 1 || (a->ksplit > 1 && (!a->partial || a->B != 1))) { set_error("conv_gemm: split-K needs partial output and B == 1"); return -1; }
   if (a->partial && a->ksplit < 1) { set_error("conv_gemm: bad ksplit"); return -1; }
   if (a->B < 1 || a->T < 1) { set_error("conv_gemm: empty batch"); return -1; }

@@ -573,3 +573,59 @@ def clip_ranks(logits, diag, col0):
     cnt = torch.empty(Bm, dtype=torch.int32, device=logits.device)
     L.check(L.load().sda_clip_ranks(_p(logits), _p(diag), _p(cnt), Bm, Bn, col0, _st()), "clip_ranks")
     return cnt
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# wav2vec 2.0 embedder stages (csrc/w2v2.hip) and the raw GEMM form of conv_gemm they share
+# ---------------------------------------------------------------------------------------------------------------
+def gemm_view(x_ptr: int, w_ptr: int, y_ptr: int, *, rows: int, K: int, Cout_p: int, x_pitch: int, w_pitch: int, x_row0: int,
+              x_rows_limit: int, dtype, bias=None, res_ptr: Optional[int] = None, gelu: bool = False,
+              w_rows_limit: Optional[int] = None):
+    """y[x_row0 + r][0:Cout_p] = sum_k x[x_row0 + r][k] * w[co][k] (+ bias)(+ res)(GELU) for r < rows, on raw device
+    addresses: conv_gemm with kernel size 1 in matrix mode.  Row r of x starts at x_ptr + (x_row0 + r) * x_pitch elements
+    and is K elements long, so x_pitch < K gives overlapping rows (an im2col view of a strided Conv1d); w row co starts at
+    w_ptr + co * w_pitch.  y rows have Cout_p elements.  The caller guarantees every address touched is allocated."""
+    a = L.ConvArgs()
+    a.x, a.w, a.bias, a.res, a.y, a.y_pre = x_ptr, w_ptr, _p(bias), res_ptr, y_ptr, None
+    a.widx, a.stats, a.partial, a.bn_x, a.bn_coef = None, None, None, None, None
+    a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = 1, rows, K, Cout_p, 1, 0
+    a.x_pitch, a.w_pitch = x_pitch, w_pitch
+    a.x_row0, a.x_sample_rows, a.x_rows_limit = x_row0, rows + L.ROW_PAD, x_rows_limit
+    a.w_rows_limit, a.ksplit = (Cout_p if w_rows_limit is None else w_rows_limit), 1
+    a.flags, a.dtype = (L.EPI_GELU if gelu else 0), dt_code(dtype)
+    L.check(L.load().sda_conv_gemm(C.byref(a), _st()), "conv_gemm(view)")
+
+
+def w2v_conv0(wave, w, bias, gamma, beta, y, T, C, K, stride, eps=1e-5):
+    L.check(L.load().sda_w2v_conv0(_p(wave), wave.numel(), _p(w), _p(bias), _p(gamma), _p(beta), _p(y), T, C, y.shape[1], K, stride,
+                                   eps, dt_code(y.dtype), _st()), "w2v_conv0")
+    return y
+
+
+def layernorm_rows(x, y, gamma, beta, T, C, eps=1e-5, gelu=False):
+    L.check(L.load().sda_layernorm_rows(_p(x), _p(y), _p(gamma), _p(beta), T, C, x.shape[1], eps, int(gelu), dt_code(x.dtype), _st()),
+            "layernorm_rows")
+    return y
+
+
+def w2v_group_split(h, xg, T, gw, G, lead):
+    L.check(L.load().sda_w2v_group_split(_p(h), _p(xg), T, h.shape[1], gw, xg.shape[2], G, xg.shape[1], lead, dt_code(h.dtype), _st()),
+            "w2v_group_split")
+
+
+def w2v_group_merge_add(h, yg, out, T, gw, G):
+    L.check(L.load().sda_w2v_group_merge_add(_p(h), _p(yg), _p(out), T, h.shape[1], gw, yg.shape[2], G, yg.shape[1],
+                                             dt_code(h.dtype), _st()), "w2v_group_merge_add")
+    return out
+
+
+def w2v_attention(q_ptr, k_ptr, vt, out, T, heads, head_dim, qk_pitch, scale):
+    L.check(L.load().sda_w2v_attention(q_ptr, k_ptr, _p(vt), _p(out), T, heads, head_dim, qk_pitch, vt.shape[1], out.shape[1],
+                                       scale, dt_code(out.dtype), _st()), "w2v_attention")
+    return out
+
+
+def w2v_mean4(a, b, c, d, T, Cc):
+    out = torch.empty((T, Cc), dtype=torch.float32, device=a.device)
+    L.check(L.load().sda_w2v_mean4(_p(a), _p(b), _p(c), _p(d), _p(out), T, Cc, a.shape[1], dt_code(a.dtype), _st()), "w2v_mean4")
+    return out
