@@ -193,6 +193,10 @@ class Wav2Vec2Embedder:
     def release_workspace(self):
         self._ws.clear()
 
+    def eval(self):
+        """`wav2vec.eval()` of the call site (gwilliams2022.py:330): the embedder is inference-only, nothing to switch."""
+        return self
+
     # ------------------------------------------------------------------ forward
     def _forward(self, wave: torch.Tensor, want_all: bool):
         """wave: 1-D fp32 on the device.  Returns (T, [row-layout hidden states kept]) — all of them when want_all (then each
