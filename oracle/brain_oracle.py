@@ -309,8 +309,9 @@ def synthetic_batch(B: int, C: int, T: int, F: int, S: int, *, seed: int = 1234)
 
 
 def train_step(P: Dict[str, Tensor], temp: Tensor, X, Y, subj, *, loc, drop_centre, d_drop=0.1,
-               stats=None, reduction="mean"):
-    """One forward+loss+backward (train.py:187-201) on leaf copies; returns (loss, Z, logits, grads)."""
+               stats=None, reduction="mean", training=True):
+    """One forward+loss+backward (train.py:187-201) on leaf copies; returns (loss, Z, logits, grads).
+    training=False: the same through an encoder in .eval() mode (BatchNorm on running statistics, no dropout)."""
     leaves = {}
     for k, v in P.items():
         if v.is_floating_point() or v.is_complex():
@@ -320,7 +321,7 @@ def train_step(P: Dict[str, Tensor], temp: Tensor, X, Y, subj, *, loc, drop_cent
     Q = dict(P)
     Q.update(leaves)
     t = temp.detach().clone().requires_grad_(True)
-    Z = brain_encoder_forward(Q, X, subj, training=True, loc=loc, drop_centre=drop_centre,
+    Z = brain_encoder_forward(Q, X, subj, training=training, loc=loc, drop_centre=drop_centre,
                               d_drop=d_drop, stats=stats)
     loss, logits = clip_loss(Y, Z, t, reduction)
     loss.backward()

@@ -303,10 +303,13 @@ class EncoderEngine:
                                                                       P[bnp + "rm"], P[bnp + "rv"], d.D2p, True, eps, momentum,
                                                                       want_bwd_coef=True)
                 else:
-                    bcoef = None
                     ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, alg_dims=alg, flags=k3_flags)
-                    mean, rstd, scale, shift = ops.bn_finalize(None, 0, count, P[bnp + "w"], P[bnp + "b"],
-                                                               P[bnp + "rm"], P[bnp + "rv"], d.D2p, False, eps, momentum)
+                    # (the backward coefficient table only when a backward may follow: eval-mode BatchNorm is then a fixed
+                    # per-channel affine map on the running statistics)
+                    mean, rstd, scale, shift, *rest = ops.bn_finalize(None, 0, count, P[bnp + "w"], P[bnp + "b"], P[bnp + "rm"],
+                                                                      P[bnp + "rv"], d.D2p, False, eps, momentum,
+                                                                      want_bwd_coef=need_grad)
+                    bcoef = rest[0] if rest else None
                 ctx.bn[bnp] = (mean, rstd, bcoef)
                 a = ops.bn_gelu_forward(h, rows(f"b{k}.a{j}", d.D2p), scale, shift, B, T)
                 bufs[f"b{k}.h{j}"], bufs[f"b{k}.a{j}"] = h, a
@@ -483,18 +486,21 @@ class EncoderEngine:
                 mean, rstd, _ = ctx.bn[bnp]
                 dh = tmp(f"dh.{k}.{j}", d.D2p)
                 world = self.world
+                # eval-mode BatchNorm (running statistics) has no batch-statistics terms in its input gradient: an infinite
+                # count zeroes them (dbeta / N, dgamma / N) while dgamma / dbeta themselves stay the plain sums, rank-local
+                sync = self.group is not None and ctx.training
                 dgam, dbet = ops.bn_gelu_backward(da1, bufs[f"b{k}.h{j}"], mean, rstd, P[bnp + "w"], P[bnp + "b"], dh, B, T,
-                                                  scratch, count=float(B) * T * world,
-                                                  allreduce=self._allreduce if self.group is not None else None, tile_stats=tstats)
+                                                  scratch, count=float(B) * T * world if ctx.training else float("inf"),
+                                                  allreduce=self._allreduce if sync else None, tile_stats=tstats)
                 # under DP the sums are already global on every rank; the gradient all-reduce (SUM) follows
-                if self.group is not None:
+                if sync:
                     dgam, dbet = dgam / world, dbet / world
                 grads[bnp + "w"], grads[bnp + "b"] = dgam[: d.D2], dbet[: d.D2]
                 src = bufs[f"b{k}.a0"] if j == 1 else x_in
                 ci, ci_p = (d.D2, d.D2p) if j == 1 else (cin, cin_p)
                 # conv0/conv1 feed a training-mode BatchNorm, which removes any per-channel constant: the bias
                 # gradient is identically zero (the reference's autograd reports rounding noise there)
-                grads[f"b{k}.c{j}b"] = null_bias[2 * k + j]
+                grads[f"b{k}.c{j}b"] = null_bias[2 * k + j] if ctx.training else bias_grad(ops.colsum(dh, B, T, scratch), d.D2)
                 res = dh if (j == 1 or k > 0) else None
                 out = tmp("da", d.D2p) if j == 1 else tmp("dxB" if flip == 0 else "dxA", ci_p)
                 da1, tstats = dgrad(dh, f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res,

@@ -270,8 +270,13 @@ class CLIPLoss(nn.Module):
         batch_size = x.size(0)
         assert batch_size > 1, "Batch size must be greater than 1."               # loss.py:40
         if not fast:
-            raise NotImplementedError("fast=False (loss.py:46-50, unscaled cosine logits) is never used by the "
-                                      "training path and is not provided by the HIP build")
+            # loss.py:46-50: logits[i][j] = cos(y_i, x_j) — the fast way's matrix TRANSPOSED and without the learned
+            # temperature (which then receives no gradient).  The symmetric loss is the same function of it, so the same
+            # kernels run with a zero log-temperature; only the returned logits are turned.
+            zero = torch.zeros(1, dtype=torch.float32, device=self.temp.device)
+            loss, logits = _ClipFn.apply(self, x, y, zero)
+            self.last_logits = logits
+            return (logits.t(), loss) if return_logits else loss
         loss, logits = _ClipFn.apply(self, x, y, self.temp)
         self.last_logits = logits
         if return_logits:

@@ -157,9 +157,6 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: "BrainEncoder", X, subject_idxs, mask, need_grad, *params):
         P = module._param_dict(params)
-        if need_grad and not module.training:
-            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented; call .train() "
-                                      "or wrap the forward in torch.no_grad()")
         ectx = module.engine.forward(P, X, subject_idxs, training=module.training, mask=mask, need_grad=need_grad)
         ctx.module, ctx.ectx, ctx.P = module, ectx, P
         ctx.nparams = len(params)
