@@ -55,6 +55,9 @@ int sda_pad_channels(int C);
 /* (B, C, T) fp32 contiguous  ->  RL rows of Cp elements of `dtype` (channel padding zero-filled; pad
  * rows are NOT touched: the caller zero-initialises the buffer once). */
 int sda_pack_rows(const float* src, void* dst, int B, int C, int T, int Cp, int dtype, void* stream);
+/* the same with padding channel `ones_channel` (C <= ones_channel < Cp) set to 1 on every valid row: a bias folded into a
+ * per-sample weight matrix rides on it (the composed SubjectBlock, models.py:111-117) */
+int sda_pack_rows_ones(const float* src, void* dst, int B, int C, int T, int Cp, int ones_channel, int dtype, void* stream);
 /* RL -> (B, C, T) fp32 contiguous */
 int sda_unpack_rows(const void* src, float* dst, int B, int C, int T, int Cp, int dtype, void* stream);
 /* (B, C, T) of `dtype`... not provided: gradients enter/leave in RL. */

@@ -50,13 +50,13 @@ static inline int stream_blocks(int B, int T, int nch) {
 // ------------------------------------------------------------------------------------------------
 template <typename E>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, E* __restrict__ dst,
-                                                        int C, int T, int Cp) {
+                                                        int C, int T, int Cp, int one_ch) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int cc = ty; cc < 64; cc += 4) {
     const int c = c0 + cc, t = t0 + tx;
-    tile[cc][tx] = (c < C && t < T) ? src[((size_t)b * C + c) * T + t] : 0.f;
+    tile[cc][tx] = (c < C && t < T) ? src[((size_t)b * C + c) * T + t] : ((c == one_ch && t < T) ? 1.f : 0.f);
   }
   __syncthreads();
   for (int rr = ty; rr < 64; rr += 4) {
@@ -745,8 +745,19 @@ extern "C" int sda_pack_rows(const float* src, void* dst, int B, int C, int T, i
   if (!src || !dst || Cp % 64 || C > Cp || B < 1) { set_error("pack_rows: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((T + 63) / 64, Cp / 64, B);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_rows_kernel<E>, grid, dim3(256), 0, st, src, (E*)dst, C, T, Cp));
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_rows_kernel<E>, grid, dim3(256), 0, st, src, (E*)dst, C, T, Cp, -1));
   return check_launch("pack_rows");
+}
+
+extern "C" int sda_pack_rows_ones(const float* src, void* dst, int B, int C, int T, int Cp, int ones_channel, int dtype,
+                                  void* stream) {
+  if (!src || !dst || Cp % 64 || C > Cp || B < 1 || ones_channel < C || ones_channel >= Cp) {
+    set_error("pack_rows_ones: bad arguments (the constant channel must be a padding channel)"); return -1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((T + 63) / 64, Cp / 64, B);
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_rows_kernel<E>, grid, dim3(256), 0, st, src, (E*)dst, C, T, Cp, ones_channel));
+  return check_launch("pack_rows_ones");
 }
 
 extern "C" int sda_unpack_rows(const void* src, float* dst, int B, int C, int T, int Cp, int dtype, void* stream) {

@@ -64,6 +64,7 @@ class EncoderCtx:
     packed_T: Dict[str, torch.Tensor] = field(default_factory=dict)
     packed_T_ready: Optional[torch.cuda.Event] = None     # side-stream packing of packed_T has finished
     glu_fused: bool = False                               # F.glu ran in conv2's epilogue: bufs hold the gate, not [value | gate]
+    composed: Optional[tuple] = None                      # composed SubjectBlock: (Wd, T1aug, Ws) fp32 factors kept for backward
 
 
 class EncoderEngine:
@@ -86,17 +87,22 @@ class EncoderEngine:
         # activation, never on each other or on the data-gradient chain: run them on a second HIP stream
         self.wgrad_side_stream = True
         self.side_stream_priority = 0        # HIP stream priority of the weight-gradient / packing stream
+        self.probe = None                    # diagnostics (tools/stream_waits.py): a list collects (label, event, event) around
+                                             # every point where the main stream waits for another stream
         self.pack_on_side_stream = True      # per-step operand packing runs beside the first layers, not in front
         self.forward_pair_tiles = True       # forward k = 3 convs (nothing competes for the CU's LDS there): two
                                              # tiles per workgroup share each weight slab — fewer LDS-DMA bytes per FLOP
         self.flat_tiles_forward = True       # k = 3 convs on the 256-row flat-tile kernel (conv3_flat.hip) where it applies
         self.fuse_glu_forward = True         # F.glu in conv2's epilogue (flat-tile kernel, D2p % 80 == 0): no [value | gate] buffer
+        self.compose_subject_block = True    # SpatialAttention, the shared 1x1 conv and the per-subject 1x1 conv as ONE per-subject
+                                             # matrix (needs a spare padding channel for the folded bias: C < Cp)
         # backward keeps the 128-row tile kernel (40 KB of LDS per workgroup): the flat kernel's two 76 KB workgroups fill a
         # CU's LDS, the weight-gradient GEMMs of the side stream then wait for the conv instead of running beside it
         # (measured in the step: +2 %; with one flat workgroup per CU: +7 %)
         self.flat_tiles_backward = False
         self.flat_backward_one_per_cu = False
         self._side = {}
+        self._const = {}                     # persistent operand buffers (composed SubjectBlock matrices)
 
     @property
     def world(self) -> int:
@@ -152,23 +158,39 @@ class EncoderEngine:
         return perm, seg, nseg
 
     @property
+    def composed(self) -> bool:
+        return bool(self.compose_subject_block and self.d.C < self.d.Cp)
+
+    @property
     def glu_fused(self) -> bool:
         return bool(self.fuse_glu_forward and self.flat_tiles_forward and self.d.D2p % 80 == 0)
 
+    def _wait(self, label: str, stream, event):
+        """stream.wait_event(event); with a probe attached, bracketed by timing events (how long the stream sat idle)."""
+        if self.probe is None:
+            stream.wait_event(event)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        stream.wait_event(event)
+        e1.record(stream)
+        self.probe.append((label, e0, e1))
+
     # ------------------------------------------------------------------ operand packing plans
     def _plans(self, P, dev):
-        key = (str(dev), self.dtype, self.glu_fused)
+        key = (str(dev), self.dtype, self.glu_fused, self.composed)
         if getattr(self, "_plan_key", None) == key:
             return self._fwd_plan, self._bwd_plan
         d = self.d
         f, b = ops.PackPlan(self.dtype, dev), ops.PackPlan(self.dtype, dev)
         glu = dict(glu_half=d.D2, glu_half_p=d.D2p)
         glu_fwd = dict(glu, glu_tile=80) if self.glu_fused else glu      # SDA_EPI_GLU's 80 value + 80 gate channels per tile
-        f.add_weight("sb_w", P["sb_w"], d.D1p, d.D1p)
-        f.add_vector("sb_b", P["sb_b"], d.D1p)
-        f.add_weight("subj_w", P["subj_w"], d.D1p, d.D1p)
-        b.add_weight("sb_w", P["sb_w"], d.D1p, d.D1p, mode=1)
-        b.add_weight("subj_w", P["subj_w"], d.D1p, d.D1p, mode=1)
+        if not self.composed:                # (the composed SubjectBlock builds its per-subject operand itself)
+            f.add_weight("sb_w", P["sb_w"], d.D1p, d.D1p)
+            f.add_vector("sb_b", P["sb_b"], d.D1p)
+            f.add_weight("subj_w", P["subj_w"], d.D1p, d.D1p)
+            b.add_weight("sb_w", P["sb_w"], d.D1p, d.D1p, mode=1)
+            b.add_weight("subj_w", P["subj_w"], d.D1p, d.D1p, mode=1)
         for k in range(5):
             cin_p = d.D1p if k == 0 else d.D2p
             for j in (0, 1):
@@ -225,7 +247,8 @@ class EncoderEngine:
             # with few (S = 1 in configs 1/4) every subject's samples are cut into r slices so that the launch still
             # has ~wgrad_target_wgs workgroups, and the r slabs of a subject are summed afterwards in fixed order.
             tile_m = 160 if d.D1p % 160 == 0 else (128 if d.D1p % 128 == 0 else 64)
-            ntiles = (d.D1p // tile_m) * (d.D1p // (128 if d.D1p % 128 == 0 else 64))
+            cin_p = d.Cp if self.composed else d.D1p       # (composed SubjectBlock: the gradient of the (D1, C) per-subject matrix)
+            ntiles = (d.D1p // tile_m) * (cin_p // (128 if cin_p % 128 == 0 else 64))
             r = int(max(1, min(max(1, B // max(1, d.S)), round(self.wgrad_target_wgs / max(1, ntiles * d.S)))))
             perm, seg = subject_segments(sidx, d.S, r)
             ctx.subj_perm = up("subj_perm", perm, dev)
@@ -261,20 +284,42 @@ class EncoderEngine:
             k3_flags |= L.CONV_FLAT_TILES
 
         # ---- SubjectBlock (models.py:111-117)
+        composed = self.composed
         Xt = rows("Xt", d.Cp)
-        ops.pack_rows(X, Xt)
+        ops.pack_rows(X, Xt, ones_channel=d.C if composed else None)
         bufs["Xt"] = Xt
         W_sa, Wp = ops.sa_weights_forward(P["z"], P["cos"], P["sin"], mask, d.D1p, d.Cp, dt, fwd_table=P.get("sa_tab_f"))
         ctx.W_sa = W_sa
-        h_sa = ops.conv_gemm(Xt, Wp, rows("h_sa", d.D1p), B=B, T=T, KS=1, dil=0, alg_dims=(d.C, d.D1))
-        bufs["h_sa"] = h_sa
-        if packed_ready is not None:
-            main.wait_event(packed_ready)
-        h_c = ops.conv_gemm(h_sa, pk["sb_w"], rows("h_c", d.D1p), B=B, T=T, KS=1, dil=0, bias=pk["sb_b"],
-                            alg_dims=(d.D1, d.D1))
-        bufs["h_c"] = h_c
-        x = ops.conv_gemm(h_c, pk["subj_w"], rows("x0", d.D1p), B=B, T=T, KS=1, dil=0, widx=ctx.widx, alg_dims=(d.D1, d.D1))
-        bufs["x0"] = x
+        if composed:
+            # models.py:111-117 is three linear maps in a row with nothing between them: x0 = W_subj[s] (W_sb (W_sa X) + b_sb).
+            # Composed per subject in fp32 parameter space — (S, D1, C + 1) with the bias riding on Xt's constant channel —
+            # one per-sample-weight GEMM replaces three, and the backward needs no data gradient at all here (X is an input):
+            # one per-subject weight gradient, then the chain rule on (S, D1, C)-sized matrices (plain library GEMMs).
+            Wd = W_sa if mask is None else W_sa * mask
+            Ws = P["subj_w"][..., 0]                                                             # (S, D1, D1)
+            T1aug = torch.cat([P["sb_w"][..., 0] @ Wd, P["sb_b"][:, None]], dim=1)            # (D1, C + 1)
+            key = ("wtot", str(dev), dt)
+            Wtot = self._const.get(key)
+            if Wtot is None:
+                Wtot = self._const[key] = torch.zeros((d.S, 1, d.D1p, d.Cp), dtype=dt, device=dev)
+            Wtot[:, 0, : d.D1, : d.C + 1].copy_(torch.matmul(Ws, T1aug))
+            if need_grad:
+                ctx.composed = (Wd, T1aug, Ws)
+            x = ops.conv_gemm(Xt, Wtot, rows("x0", d.D1p), B=B, T=T, KS=1, dil=0, widx=ctx.widx,
+                              alg_dims=(d.C, d.D1))
+            bufs["x0"] = x
+            if packed_ready is not None:
+                self._wait("packed operands (forward)", main, packed_ready)
+        else:
+            h_sa = ops.conv_gemm(Xt, Wp, rows("h_sa", d.D1p), B=B, T=T, KS=1, dil=0, alg_dims=(d.C, d.D1))
+            bufs["h_sa"] = h_sa
+            if packed_ready is not None:
+                self._wait("packed operands (forward)", main, packed_ready)
+            h_c = ops.conv_gemm(h_sa, pk["sb_w"], rows("h_c", d.D1p), B=B, T=T, KS=1, dil=0, bias=pk["sb_b"],
+                                alg_dims=(d.D1, d.D1))
+            bufs["h_c"] = h_c
+            x = ops.conv_gemm(h_c, pk["subj_w"], rows("x0", d.D1p), B=B, T=T, KS=1, dil=0, widx=ctx.widx, alg_dims=(d.D1, d.D1))
+            bufs["x0"] = x
 
         # ---- 5 ConvBlocks (models.py:152-166)
         ntile = B * ops.n_t_tiles(T)
@@ -354,7 +399,7 @@ class EncoderEngine:
         B, T, bufs = ctx.B, ctx.T, ctx.bufs
         dev = dZt.device
         if getattr(ctx, "packed_T_ready", None) is not None:
-            torch.cuda.current_stream(dev).wait_event(ctx.packed_T_ready)
+            self._wait("packed operands (backward)", torch.cuda.current_stream(dev), ctx.packed_T_ready)
         grads: Dict[str, torch.Tensor] = {}
         scratch = ops.reduce_scratch(max(d.Fp, 2 * d.D2p, d.F1p), dev)
         pending = []                          # (work, names) of in-flight gradient all-reduces
@@ -414,7 +459,7 @@ class EncoderEngine:
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record(side)
-                main.wait_event(ev)
+                self._wait("weight-gradient stream joined", main, ev)
 
         def wgrad(dy, x, KS, dil, Cout, Cin, **glu):
             Cout_p, Cin_p = dy.shape[1], x.shape[1]
@@ -520,6 +565,27 @@ class EncoderEngine:
             if r > 1:
                 slabs = ops.reduce_slabs(slabs.view(r, -1)).view(d.S, 1, d.D1p, d.D1p)
             return ops.unpack_conv_wgrad(slabs, d.S, d.D1, d.D1, 1, d.D1p, d.D1p)
+        if ctx.composed is not None:
+            Wd, T1aug, Ws = ctx.composed
+            r = ctx.subj_slices
+            slabs = ops.wgrad_gemm(dhs, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg,
+                                   nseg=r * d.S)                        # (r*S, 1, D1p, Cp): dL/dW_tot[s], column C = dL/db_tot[s]
+            if r > 1:
+                slabs = ops.reduce_slabs(slabs.view(r, -1))
+            G = slabs.view(d.S, d.D1p, d.Cp)[:, : d.D1, : d.C + 1]                            # (S, D1, C + 1)
+            grads["subj_w"] = torch.matmul(G, T1aug.t()).unsqueeze(-1)                         # W_tot = W_subj T1aug
+            dT1 = Ws.permute(2, 0, 1).reshape(d.D1, d.S * d.D1) @ G.reshape(d.S * d.D1, d.C + 1)   # sum_s W_subj[s]^T G[s]
+            grads["sb_b"] = dT1[:, d.C].contiguous()
+            dT1 = dT1[:, : d.C]
+            grads["sb_w"] = (dT1 @ Wd.t()).unsqueeze(-1)
+            dWd = (P["sb_w"][..., 0].t() @ dT1).contiguous()
+            grads["z"] = ops.sa_weights_backward(dWd, ctx.W_sa, ctx.mask, P["cosT"], P["sinT"], P["z"].shape[1],
+                                                 bwd_table=P.get("sa_tab_b"))
+            flush(["subj_w", "sb_w", "sb_b", "z"])
+            join_side()
+            for work in pending:
+                work.wait()
+            return grads
         grads["subj_w"] = on_side(subj_wgrad)
         dh_c, _ = dgrad(dhs, "subj_w", P["subj_w"], d.D1p, d.D1p, tmp("dh_c", d.D1p), 1, 0, widx=ctx.widx)
         grads["sb_w"] = wgrad(dh_c, bufs["h_sa"], 1, 0, d.D1, d.D1)

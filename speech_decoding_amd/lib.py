@@ -54,6 +54,7 @@ SIGNATURES = {
     "sda_device_count": (i32, []),
     "sda_upload_words": (i32, [vp, vp, i64, vp]),
     "sda_pack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sda_pack_rows_ones": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "sda_unpack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sda_rows_sumsq": (i32, [vp, vp, vp, i32, i64, i64, i32, vp]),
     "sda_rows_sumsq_from_stats": (i32, [vp, i32, i32, vp, i32, vp]),

@@ -98,11 +98,16 @@ def rows_view(buf: torch.Tensor, B: int, C: int, T: int) -> torch.Tensor:
     return buf.as_strided((B, C, T), (Tp * Cp, 1, Cp), L.ROW_PAD * Cp)
 
 
-def pack_rows(src: torch.Tensor, dst: torch.Tensor):
+def pack_rows(src: torch.Tensor, dst: torch.Tensor, ones_channel: Optional[int] = None):
+    """(B, C, T) fp32 -> row layout; with `ones_channel` that padding channel is 1 on every valid row."""
     _need_cuda(src, dst)
     B, Cc, T = src.shape
     src = src.contiguous().float()
-    L.check(L.load().sda_pack_rows(_p(src), _p(dst), B, Cc, T, dst.shape[1], dt_code(dst.dtype), _st()), "pack_rows")
+    if ones_channel is None:
+        L.check(L.load().sda_pack_rows(_p(src), _p(dst), B, Cc, T, dst.shape[1], dt_code(dst.dtype), _st()), "pack_rows")
+    else:
+        L.check(L.load().sda_pack_rows_ones(_p(src), _p(dst), B, Cc, T, dst.shape[1], ones_channel, dt_code(dst.dtype), _st()),
+                "pack_rows_ones")
 
 
 def unpack_rows(src: torch.Tensor, B: int, Cc: int, T: int) -> torch.Tensor:
