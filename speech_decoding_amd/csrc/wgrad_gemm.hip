@@ -14,8 +14,20 @@
 // segment per subject (final result, no reduction), shared weights use ~CU-count segments + reduce_slabs.
 #include "sd_common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace sda {
 
+namespace {
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F> __device__ __forceinline__ void wg_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    wg_static_for<B + 1, E>(f);
+  }
+}
+}  // namespace
 
 // Rows per MFMA K-step: 32 (bf16) / 16 (fp32).  A staged K-chunk holds KM of them.
 template <typename E> struct WK;
@@ -205,29 +217,84 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
     }
   };
 
-  // this wave's LDS-DMA pieces per chunk (asm DMA is not tracked by hipcc: the counted waits below are ours)
-  const int my_pieces = ((G::DY_PIECES - wid + 3) >> 2) + ((x_pieces - wid + 3) >> 2);
-  const int keep = (NS - 2) * my_pieces;                  // pieces of younger chunks that may still be in flight
+  // Fast staging of whole chunks.  Inside a chunk the (row, 16-byte chunk) a lane fetches for the wave's i-th piece never
+  // changes, so its byte offset is computed ONCE; per chunk only a wave-uniform base moves (first row of the chunk), and a
+  // piece is a scalar base + one offset register (lds_dma16_sv) — no per-lane address arithmetic left in the loop.  That
+  // makes an issue cheap enough to sit BETWEEN the MFMA groups of the chunk being consumed (it costs the wave's issue slot
+  // while the matrix pipe drains the MFMAs queued before it) instead of in front of them.  Chunks that run past the
+  // sample's T rows (dy must read the zero row there) or past the buffer keep the per-lane path, issued up front.
+  constexpr int NDY = (G::DY_PIECES + 3) / 4;
+  constexpr int NX = (G::X_BYTES / 1024 + 3) / 4;
+  uint32_t vdy[NDY], vx[NX];
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < total) stage(s, s);
+  for (int i = 0; i < NDY; ++i) {
+    const int byte = (wid + 4 * i) * 1024 + lane * 16;
+    const int r = byte / G::RB_M;
+    const int c = ((byte - r * G::RB_M) >> 4) ^ chunk_xor<E, G::RB_M>(r);
+    vdy[i] = (uint32_t)(((size_t)r * a.dy_pitch + (size_t)c * PER16) * sizeof(E));
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int byte = (wid + 4 * i) * 1024 + lane * 16;
+    const int r = byte / G::RB_N;
+    const int c = ((byte - r * G::RB_N) >> 4) ^ chunk_xor<E, G::RB_N>(r);
+    vx[i] = (uint32_t)(((size_t)r * a.x_pitch + (size_t)c * PER16) * sizeof(E));
+  }
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const E* dy_base = dyg;            // wave-uniform bases of the chunk being staged (fast path)
+  const E* x_base = xg;
+  uint32_t nxt_off = 0;
+  // chunk `it` -> is it a fast one?  sets the bases; the slow path stages it at once
+  auto prepare = [&](int it, int buf) -> bool {
+    const int si = it / nchunk, ch = it - si * nchunk;
+    if (si != staged_si) {
+      staged_si = si;
+      staged_b = a.perm ? __builtin_amdgcn_readfirstlane(a.perm[s_beg + si]) : (s_beg + si);
+    }
+    const long srow = a.row0 + (long)staged_b * a.sample_rows;
+    const int t0 = ch * KT;
+    const long xrow0 = srow + t0 - halo;
+    if (t0 + KT <= a.T && xrow0 >= 0 && xrow0 + KT + 2 * halo <= a.rows_limit) {
+      dy_base = dyg + (size_t)(srow + t0) * a.dy_pitch + co0;
+      x_base = xg + (size_t)xrow0 * a.x_pitch + ci0;
+      nxt_off = (uint32_t)(buf * G::STAGE);
+      return true;
+    }
+    stage(it, buf);
+    return false;
+  };
+  auto issue_piece = [&](auto jc) {            // j-th piece of this wave of the chunk prepared last
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < NDY) {
+      const int pc = wid + 4 * j;
+      if (pc < G::DY_PIECES) lds_dma16_sv(dy_base, vdy[j], lds_base + nxt_off + pc * 1024);
+    } else if constexpr (j < NDY + NX) {
+      const int pc = wid + 4 * (j - NDY);
+      if (pc < x_pieces) lds_dma16_sv(x_base, vx[j - NDY], lds_base + nxt_off + G::DY_BYTES + pc * 1024);
+    }
+  };
+  constexpr int NPW = NDY + NX;                // pieces per wave and chunk (upper bound)
+  constexpr int NGRP = (KT / KSTEP) * KS;      // MFMA groups per chunk
+  constexpr int PER_GRP = (NPW + NGRP - 1) / NGRP;
+
+  static_assert(NS == 2, "the chunk loop below is written for two LDS stages");
+  if (0 < total) stage(0, 0);
   int cur = 0;
   for (int it = 0; it < total; ++it) {
-    if (NS > 2 && it + NS - 2 < total) wait_vmcnt_dyn(keep);   // own pieces of chunk `it` landed
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of chunk `it` landed
     __builtin_amdgcn_s_barrier();                       // everyone's landed; chunk it-1 fully consumed
-    if (it + NS - 1 < total) stage(it + NS - 1, (cur + NS - 1) % NS);
+    const bool fast = (it + 1 < total) && prepare(it + 1, cur ^ 1);
     const unsigned char* dys = smem + cur * G::STAGE;
-    cur = (cur + 1 == NS) ? 0 : cur + 1;
+    cur ^= 1;
     const unsigned char* xs = dys + G::DY_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < KT / KSTEP; ++kk) {
+    wg_static_for<0, KT / KSTEP>([&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
       uint4 af[MREP];
 #pragma unroll
       for (int m = 0; m < MREP; ++m)
         af[m] = TrOp<E, G::RB_M>::get(dys, kk * KSTEP, wave_m * (TILE_M / 2) + m * 16, lane);
-#pragma unroll
-      for (int tap = 0; tap < KS; ++tap) {
+      wg_static_for<0, KS>([&](auto tc) {
+        constexpr int tap = decltype(tc)::value;
         uint4 bf[NREP];
 #pragma unroll
         for (int n = 0; n < NREP; ++n)
@@ -236,8 +303,12 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
         for (int m = 0; m < MREP; ++m)
 #pragma unroll
           for (int n = 0; n < NREP; ++n) acc[tap][m][n] = mma16<E>(af[m], bf[n], acc[tap][m][n]);
-      }
-    }
+        if (fast) {
+          constexpr int grp = kk * KS + tap;
+          wg_static_for<grp * PER_GRP, (grp + 1) * PER_GRP < NPW ? (grp + 1) * PER_GRP : NPW>(issue_piece);
+        }
+      });
+    });
   }
 
   if (!a.out_e) {

@@ -45,7 +45,7 @@ def main():
                 dy = ops.new_rows(B, T, cout, dtype, dev); dy.normal_()
                 tile_m = 160 if cout % 160 == 0 else 128
                 ntiles = (cout // tile_m) * (cin // 64)
-                nseg = max(1, min(B, round(256 / ntiles)))
+                nseg = max(1, min(B, round(int(os.environ.get("WGS", 256)) / ntiles)))
                 import numpy as np
                 seg = torch.from_numpy(np.floor(np.linspace(0, B, nseg + 1)).astype(np.int32)).to(dev)
                 perm = torch.arange(B, dtype=torch.int32, device=dev)
