@@ -29,6 +29,29 @@ struct RowWalk {
   }
 };
 
+// The same walk reduced to what the inner loop needs: a 32-bit ELEMENT offset that advances by a constant and takes the
+// pad rows in one extra add when the time index wraps (row-layout buffers stay below 2^32 elements: the launchers check),
+// and the number of rows this thread owns — so the loop body has no validity predicates and no 64-bit multiplies.
+struct RowCursor {
+  uint32_t off, step, wrap;
+  int t, T, RG, n;
+  __device__ RowCursor(int r0, int r1, int rg, int RG_, int T_, int Cp, int col) : T(T_), RG(RG_) {
+    const int first = r0 + rg;
+    n = first < r1 ? (r1 - first + RG_ - 1) / RG_ : 0;
+    const int b = first / T_;
+    t = first - b * T_;
+    off = (uint32_t)(b * rows_tp(T_) + PAD + t) * (uint32_t)Cp + (uint32_t)col;
+    step = (uint32_t)RG_ * (uint32_t)Cp;
+    wrap = (uint32_t)PAD * (uint32_t)Cp;
+  }
+  __device__ uint32_t take() {              // offset of the current row; moves to the next one
+    const uint32_t o = off;
+    off += step; t += RG;
+    while (t >= T) { t -= T; off += wrap; }
+    return o;
+  }
+};
+
 // valid-row range of this workgroup: rows split evenly over the grid
 __device__ inline void block_rows(int B, int T, int& r0, int& r1) {
   const int rows = B * T;
@@ -38,6 +61,9 @@ __device__ inline void block_rows(int B, int T, int& r0, int& r1) {
 }
 
 // grid of a streaming pass: about 32 rows per thread-row group, at most 8 workgroups per CU
+// RowCursor's offsets are 32-bit element indices
+static inline bool fits_u32(int B, int T, long width) { return (unsigned long long)rows_alloc(B, T) * (unsigned long long)width < (1ull << 32); }
+
 static inline int stream_blocks(int B, int T, int nch) {
   const long rows = (long)B * T;
   const int RG = nch >= 256 ? 1 : 256 / nch;
@@ -354,25 +380,30 @@ __global__ __launch_bounds__(256) void bn_gelu_fwd_kernel(const E* __restrict__ 
       *reinterpret_cast<float4*>(sc + q4 * 4) = *reinterpret_cast<const float4*>(scale + ch * CH + q4 * 4);
       *reinterpret_cast<float4*>(sh + q4 * 4) = *reinterpret_cast<const float4*>(shift + ch * CH + q4 * 4);
     }
-    RowWalk w(r0 + rg, r1, RG, T);
-    while (w.valid()) {
-      size_t off[U];
-      bool ok[U];
+    auto one = [&](float* v) {
+#pragma unroll
+      for (int j = 0; j < CH; j += 2) {
+        const f32x2 o = gelu_pair<E>(fma2(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
+        v[j] = o.x; v[j + 1] = o.y;
+      }
+    };
+    RowCursor w(r0, r1, rg, RG, T, Cp, ch * CH);
+    for (; w.n >= U; w.n -= U) {
+      uint32_t off[U];
       float v[U][CH];
 #pragma unroll
-      for (int u = 0; u < U; ++u) { ok[u] = w.valid(); off[u] = w.mem_row() * Cp + ch * CH; w.next(); }
+      for (int u = 0; u < U; ++u) off[u] = w.take();
 #pragma unroll
-      for (int u = 0; u < U; ++u) if (ok[u]) Vec16<E>::load(x + off[u], v[u]);
+      for (int u = 0; u < U; ++u) Vec16<E>::load(x + off[u], v[u]);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (!ok[u]) continue;
-#pragma unroll
-        for (int j = 0; j < CH; j += 2) {
-          const f32x2 o = gelu_pair<E>(fma2(f32x2{v[u][j], v[u][j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
-          v[u][j] = o.x; v[u][j + 1] = o.y;
-        }
-        Vec16<E>::store(y + off[u], v[u]);
-      }
+      for (int u = 0; u < U; ++u) { one(v[u]); Vec16<E>::store(y + off[u], v[u]); }
+    }
+    for (; w.n > 0; --w.n) {
+      const uint32_t off = w.take();
+      float v[CH];
+      Vec16<E>::load(x + off, v);
+      one(v);
+      Vec16<E>::store(y + off, v);
     }
   }
 }
@@ -469,11 +500,13 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
 #pragma unroll
   for (int j = 0; j < CH; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
   if (rg < RG) {
-    for (RowWalk w((int)r0 + rg, (int)r1, RG, T); w.valid(); w.next()) {
-      const size_t row = w.mem_row();
+    RowCursor w((int)r0, (int)r1, rg, RG, T, Ch, ch * CH);       // offsets in Ch-wide rows; 2*Ch-wide rows: 2 * off - ch * CH
+#pragma unroll 2
+    for (; w.n > 0; --w.n) {
+      const uint32_t off = w.take(), off2 = 2 * off - ch * CH;
       float d[CH], xv[CH], o0[CH], o1[CH];
-      Vec16<E>::load(dy + row * Ch + ch * CH, d);
-      Vec16<E>::load(x + row * xw + ch * CH, xv);
+      Vec16<E>::load(dy + off, d);
+      Vec16<E>::load(x + (MODE == 1 ? off2 : off), xv);
       if (MODE == 0) {
 #pragma unroll
         for (int j = 0; j < CH; j += 2) {
@@ -481,11 +514,11 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
           o0[j] = o.x; o0[j + 1] = o.y;
           a0[j] += o.x; a0[j + 1] += o.y;
         }
-        Vec16<E>::store(dx + row * Ch + ch * CH, o0);
+        Vec16<E>::store(dx + off, o0);
       } else {
         float g[CH];
-        if (MODE == 1) Vec16<E>::load(x + row * xw + Ch + ch * CH, g);
-        else Vec16<E>::load(gate + row * Ch + ch * CH, g);
+        if (MODE == 1) Vec16<E>::load(x + off2 + Ch, g);
+        else Vec16<E>::load(gate + off, g);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           const float sg = sigmoid_f(g[j]);
@@ -494,8 +527,8 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
           a0[j] += o0[j];
           a1[j] += o1[j];
         }
-        Vec16<E>::store(dx + row * dxw + ch * CH, o0);
-        Vec16<E>::store(dx + row * dxw + Ch + ch * CH, o1);
+        Vec16<E>::store(dx + off2, o0);
+        Vec16<E>::store(dx + off2 + Ch, o1);
       }
     }
   }
@@ -586,27 +619,33 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restr
       cq[j] = ca[j] * rs * coef[5 * Cp + k];
       cp[j] = ca[j] * coef[4 * Cp + k] - cq[j] * mu;
     }
-    RowWalk w(r0 + rg, r1, RG, T);
-    while (w.valid()) {
-      size_t off[U];
-      bool ok[U];
+    auto one = [&](float* d, const float* xv) {
+#pragma unroll
+      for (int j = 0; j < CH; j += 2) {
+        const f32x2 xx = {xv[j], xv[j + 1]}, a2 = {ca[j], ca[j + 1]};
+        const f32x2 g = f32x2{d[j], d[j + 1]} * gelu_grad_pair<E>(fma2(a2, xx, f32x2{cb[j], cb[j + 1]}));
+        const f32x2 o = fma2(a2, g, -fma2(f32x2{cq[j], cq[j + 1]}, xx, f32x2{cp[j], cp[j + 1]}));
+        d[j] = o.x; d[j + 1] = o.y;
+      }
+    };
+    RowCursor w(r0, r1, rg, RG, T, Cp, ch * CH);
+    for (; w.n >= U; w.n -= U) {
+      uint32_t off[U];
       float d[U][CH], xv[U][CH];
 #pragma unroll
-      for (int u = 0; u < U; ++u) { ok[u] = w.valid(); off[u] = w.mem_row() * Cp + ch * CH; w.next(); }
+      for (int u = 0; u < U; ++u) off[u] = w.take();
 #pragma unroll
-      for (int u = 0; u < U; ++u) if (ok[u]) { Vec16<E>::load(dy + off[u], d[u]); Vec16<E>::load(x + off[u], xv[u]); }
+      for (int u = 0; u < U; ++u) { Vec16<E>::load(dy + off[u], d[u]); Vec16<E>::load(x + off[u], xv[u]); }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (!ok[u]) continue;
-#pragma unroll
-        for (int j = 0; j < CH; j += 2) {
-          const f32x2 xx = {xv[u][j], xv[u][j + 1]}, a2 = {ca[j], ca[j + 1]};
-          const f32x2 g = f32x2{d[u][j], d[u][j + 1]} * gelu_grad_pair<E>(fma2(a2, xx, f32x2{cb[j], cb[j + 1]}));
-          const f32x2 o = fma2(a2, g, -fma2(f32x2{cq[j], cq[j + 1]}, xx, f32x2{cp[j], cp[j + 1]}));
-          d[u][j] = o.x; d[u][j + 1] = o.y;
-        }
-        Vec16<E>::store(dx + off[u], d[u]);
-      }
+      for (int u = 0; u < U; ++u) { one(d[u], xv[u]); Vec16<E>::store(dx + off[u], d[u]); }
+    }
+    for (; w.n > 0; --w.n) {
+      const uint32_t off = w.take();
+      float d[CH], xv[CH];
+      Vec16<E>::load(dy + off, d);
+      Vec16<E>::load(x + off, xv);
+      one(d, xv);
+      Vec16<E>::store(dx + off, d);
     }
   }
 }
@@ -623,27 +662,24 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const E* __restrict__ x, E
   block_rows(B, T, r0, r1);
   for (int c = threadIdx.x; c < RG * nch; c += 256) {
     const int ch = c % nch, rg = c / nch;
-    RowWalk w(r0 + rg, r1, RG, T);
-    while (w.valid()) {
-      size_t row[U];
-      bool ok[U];
-      float a[U][CH], g[U][CH];
+    RowCursor w(r0, r1, rg, RG, T, Ch, ch * CH);            // offsets in the Ch-wide output; the input row is twice as wide
+    auto one = [&](uint32_t off) {
+      float a[CH], g[CH];
+      const uint32_t xo = 2 * off - ch * CH;                // row * 2 Ch + ch * CH
+      Vec16<E>::load(x + xo, a);
+      Vec16<E>::load(x + xo + Ch, g);
 #pragma unroll
-      for (int u = 0; u < U; ++u) { ok[u] = w.valid(); row[u] = w.mem_row(); w.next(); }
+      for (int j = 0; j < CH; ++j) a[j] *= sigmoid_f(g[j]);
+      Vec16<E>::store(y + off, a);
+    };
+    for (; w.n >= U; w.n -= U) {
+      uint32_t off[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (ok[u]) {
-          Vec16<E>::load(x + row[u] * 2 * Ch + ch * CH, a[u]);
-          Vec16<E>::load(x + row[u] * 2 * Ch + Ch + ch * CH, g[u]);
-        }
+      for (int u = 0; u < U; ++u) off[u] = w.take();
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (!ok[u]) continue;
-#pragma unroll
-        for (int j = 0; j < CH; ++j) a[u][j] *= sigmoid_f(g[u][j]);
-        Vec16<E>::store(y + row[u] * Ch + ch * CH, a[u]);
-      }
+      for (int u = 0; u < U; ++u) one(off[u]);
     }
+    for (; w.n > 0; --w.n) one(w.take());
   }
 }
 
@@ -896,7 +932,7 @@ extern "C" int sda_bn_finalize(const float* partial, int ntiles, double count, c
 
 extern "C" int sda_bn_gelu_forward(const void* x, void* y, const float* scale, const float* shift, int B, int T,
                                    int Cp, int dtype, void* stream) {
-  if (!x || !y || !scale || !shift || Cp % 64) { set_error("bn_gelu_forward: bad arguments"); return -1; }
+  if (!x || !y || !scale || !shift || Cp % 64 || !fits_u32(B, T, Cp)) { set_error("bn_gelu_forward: bad arguments"); return -1; }
   SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_fwd_kernel<E>, dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, (hipStream_t)stream,
                                          (const E*)x, (E*)y, scale, shift, B, T, Cp));
   return check_launch("bn_gelu_forward");
@@ -930,7 +966,7 @@ extern "C" int sda_bn_gelu_backward_apply(const void* dy, const void* x, const f
                                           const float* gamma, const float* beta, int C, const float* dgamma,
                                           const float* dbeta, double count, float* coef, void* dx, int B, int T, int Cp,
                                           int dtype, void* stream) {
-  if (!dy || !x || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !coef || !dx || Cp % 64 || count < 1.0) {
+  if (!dy || !x || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !coef || !dx || Cp % 64 || count < 1.0 || !fits_u32(B, T, Cp)) {
     set_error("bn_gelu_backward_apply: bad arguments"); return -1;
   }
   const float inv_count = (float)(1.0 / count);
@@ -947,7 +983,7 @@ extern "C" int sda_bn_gelu_backward_from_stats(const float* partial, int nrows, 
                                               const float* beta, int C, double count, float* dgamma, float* dbeta,
                                               float* coef, void* dx, int B, int T, int Cp, int dtype, void* stream) {
   if (!partial || nrows < 1 || !dy || !x || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !coef || !dx ||
-      Cp % 64 || count < 1.0) {
+      Cp % 64 || count < 1.0 || !fits_u32(B, T, Cp)) {
     set_error("bn_gelu_backward_from_stats: bad arguments"); return -1;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -973,7 +1009,7 @@ extern "C" int sda_colsum(const void* x, float* out, float* scratch, int B, int 
 extern "C" int sda_reduce_scratch_floats(int Cp) { return RED_MAX_BLOCKS * 2 * Cp; }
 
 extern "C" int sda_glu_forward(const void* x, void* y, int B, int T, int Ch, int dtype, void* stream) {
-  if (!x || !y || Ch % 64) { set_error("glu_forward: bad arguments"); return -1; }
+  if (!x || !y || Ch % 64 || !fits_u32(B, T, 2L * Ch)) { set_error("glu_forward: bad arguments"); return -1; }
   SDA_DISPATCH(dtype, hipLaunchKernelGGL(glu_fwd_kernel<E>, dim3(stream_blocks(B, T, Ch / Vec16<E>::N)), dim3(256), 0, (hipStream_t)stream,
                                          (const E*)x, (E*)y, B, T, Ch));
   return check_launch("glu_forward");
@@ -995,7 +1031,7 @@ extern "C" int sda_gelu_backward(const void* u, const void* dz, void* du, int B,
 
 extern "C" int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, float* colsum, float* scratch, int B, int T,
                                        int Ch, int dtype, void* stream) {
-  if (!x || !dy || !dx || !colsum || !scratch || Ch % 64 || Ch > 1024) { set_error("glu_backward_colsum: bad arguments"); return -1; }
+  if (!x || !dy || !dx || !colsum || !scratch || Ch % 64 || Ch > 1024 || !fits_u32(B, T, 2L * Ch)) { set_error("glu_backward_colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
   const size_t lds = (size_t)(256 / (Ch / (dtype == SDA_F32 ? 4 : 8))) * 2 * Ch * sizeof(float);
@@ -1007,7 +1043,7 @@ extern "C" int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, 
 
 extern "C" int sda_glu_backward_colsum_og(const void* out, const void* gate, const void* dy, void* dx, float* colsum,
                                           float* scratch, int B, int T, int Ch, int dtype, void* stream) {
-  if (!out || !gate || !dy || !dx || !colsum || !scratch || Ch % 64 || Ch > 1024) { set_error("glu_backward_colsum_og: bad arguments"); return -1; }
+  if (!out || !gate || !dy || !dx || !colsum || !scratch || Ch % 64 || Ch > 1024 || !fits_u32(B, T, 2L * Ch)) { set_error("glu_backward_colsum_og: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
   const size_t lds = (size_t)(256 / (Ch / (dtype == SDA_F32 ? 4 : 8))) * 2 * Ch * sizeof(float);
@@ -1019,7 +1055,7 @@ extern "C" int sda_glu_backward_colsum_og(const void* out, const void* gate, con
 
 extern "C" int sda_gelu_backward_colsum(const void* u, const void* dz, void* du, float* colsum, float* scratch, int B, int T,
                                         int Cp, int dtype, void* stream) {
-  if (!u || !dz || !du || !colsum || !scratch || Cp % 64 || Cp > 1024) { set_error("gelu_backward_colsum: bad arguments"); return -1; }
+  if (!u || !dz || !du || !colsum || !scratch || Cp % 64 || Cp > 1024 || !fits_u32(B, T, Cp)) { set_error("gelu_backward_colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
   const size_t lds = (size_t)(256 / (Cp / (dtype == SDA_F32 ? 4 : 8))) * 2 * Cp * sizeof(float);

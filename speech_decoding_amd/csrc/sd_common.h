@@ -36,6 +36,14 @@ __device__ inline uint16_t f2bf(float f) {
   return *reinterpret_cast<uint16_t*>(&b);
 }
 
+// two floats -> two bf16 in one register (ONE v_cvt_pk_bf16_f32, round to nearest even; element 0 in the low half)
+__device__ inline uint32_t pack_bf16x2(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t p = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, p);
+}
+
 // two fp16 values packed in one register <-> floats (v_cvt_f32_f16 / v_cvt_f16_f32, round to nearest even)
 __device__ inline float2 h2_to_f2(uint32_t w) {
   const f16x2 h = __builtin_bit_cast(f16x2, w);
@@ -123,7 +131,7 @@ template <> struct Vec16<uint16_t> {
   __device__ static void store(uint16_t* p, const float* v) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
   __device__ static float round(float x) { return bf2f(f2bf(x)); }
