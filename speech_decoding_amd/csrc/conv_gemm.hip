@@ -471,6 +471,9 @@ static int dispatch_conv(const sda_conv_args& a, hipStream_t st) {
     return launch_conv3_flat(a, st);
   }
   if (a.flags & SDA_EPI_GLU) { set_error("conv_gemm: SDA_EPI_GLU needs SDA_CONV_FLAT_TILES, kernel size 3 and Cout_p % 160 == 0"); return -1; }
+  // 1x1 convs whose width divides both ways (640): 128-channel tiles (conv_final1 forward 125 -> 113 us, conv_final2's data
+  // gradient 225 -> 195 us; the k = 3 convs and the statistics-row contract stay on 160)
+  if (a.KS == 1 && a.Cout_p % 128 == 0 && !a.stats) return dispatch_conv_nt<E, 128>(a, st);
   if (a.Cout_p % 160 == 0) return dispatch_conv_nt<E, 160>(a, st);
   if (a.Cout_p % 128 == 0) return dispatch_conv_nt<E, 128>(a, st);
   return dispatch_conv_nt<E, 64>(a, st);

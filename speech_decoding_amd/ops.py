@@ -274,7 +274,10 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 
 
-def conv_tile_co(Cout_p: int) -> int:
+def conv_tile_co(Cout_p: int, KS: int = 3, stats: bool = False) -> int:
+    """Output-channel tile sda_conv_gemm picks (labels of the kernel timer; mirrors dispatch_conv in conv_gemm.hip)."""
+    if KS == 1 and Cout_p % 128 == 0 and not stats:
+        return 128
     return 160 if Cout_p % 160 == 0 else (128 if Cout_p % 128 == 0 else 64)
 
 
@@ -308,7 +311,7 @@ def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=N
         e0.record()
         L.check(L.load().sda_conv_gemm(C.byref(a), _st()), "conv_gemm")
         e1.record()
-        TIMER.records.append((("conv_gemm", str(x.dtype).replace("torch.", ""), conv_tile_co(Cout_p), KS),
+        TIMER.records.append((("conv_gemm", str(x.dtype).replace("torch.", ""), conv_tile_co(Cout_p, KS, stats is not None), KS),
                               2.0 * B * T * KS * cin * cout, e0, e1))
         return y
     L.check(L.load().sda_conv_gemm(C.byref(a), _st()), "conv_gemm")
