@@ -360,13 +360,17 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
 
 template <typename E, int TILE_M, int KS, int TN, int KM = 2, int NS = 2>
 static int launch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
-  constexpr int lds = WGeom<E, TILE_M, KS, TN, KM, NS>::LDS;
+  using WG_ = WGeom<E, TILE_M, KS, TN, KM, NS>;
+  constexpr int lds_max = WG_::LDS;
+  // the fp32 staging of the typed epilogue only where there is one: a slab-output launch that asks for less LDS leaves
+  // room on the CU for the other stream's workgroups
+  const int lds = a.out_e ? lds_max : NS * WG_::STAGE;
   static bool attr_done = false;
   auto kern = wgrad_gemm_kernel<E, TILE_M, KS, TN, KM, NS>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            lds) != hipSuccess) {
-      set_error("wgrad_gemm: cannot reserve %d bytes of LDS", lds);
+                            lds_max) != hipSuccess) {
+      set_error("wgrad_gemm: cannot reserve %d bytes of LDS", lds_max);
       return -3;
     }
     attr_done = true;
