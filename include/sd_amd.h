@@ -297,9 +297,11 @@ int sda_layernorm_rows(const void* x, void* y, const float* gamma, const float* 
  * group_rows rows x gwp channels; rows outside [lead, lead + T) and channels >= gw must already be zero) */
 int sda_w2v_group_split(const void* h, void* xg, int T, int Hp, int gw, int gwp, int G, long group_rows, int lead,
                         int dtype, void* stream);
-/* ... output side: out[t][g*gw + c] = h[t][g*gw + c] + yg[g][SDA_ROW_PAD + t][c] */
+/* ... output side: out[t][g*gw + c] = h[t][g*gw + c] + f(yg[g][SDA_ROW_PAD + t][c] + bias[g*gw + c]), f = GELU when `gelu`
+ * (bias fp32 [G*gw] or NULL).  The G per-group GEMMs between the two are ONE sda_conv_gemm launch: the groups are its
+ * "samples" (B = G, sample stride group_rows, widx = 0..G-1 selects the group's weights) */
 int sda_w2v_group_merge_add(const void* h, const void* yg, void* out, int T, int Hp, int gw, int gwp, int G, long yg_rows,
-                            int dtype, void* stream);
+                            const float* bias, int gelu, int dtype, void* stream);
 /* out = softmax(q k^T * scale) v per head (no mask): q, k row layout with pitch qk_pitch, head h in columns
  * [64h, 64h+64); vt = V transposed, plain matrix [heads*64][vt_pitch >= T rounded up to 64] (columns >= T finite);
  * out row layout with pitch out_pitch.  head_dim must be 64 */

@@ -136,11 +136,12 @@ __global__ __launch_bounds__(256) void group_split_kernel(const E* __restrict__ 
   }
 }
 
-// h_out[t][g * gw + c] = h[t][g * gw + c] + yg[g][PAD + t][c]   (yg: G row-layout buffers of gwp channels, `yg_rows` rows each)
+// h_out[t][g * gw + c] = h[t][g * gw + c] + f(yg[g][PAD + t][c] + bias[g * gw + c]),  f = GELU when `gelu`
+// (yg: G row-layout buffers of gwp channels, `yg_rows` rows each; bias may be NULL)
 template <typename E>
 __global__ __launch_bounds__(256) void group_merge_add_kernel(const E* __restrict__ h, const E* __restrict__ yg,
                                                               E* __restrict__ out, int T, int Hp, int gw, int gwp, int G,
-                                                              long yg_rows) {
+                                                              long yg_rows, const float* __restrict__ bias, int gelu) {
   constexpr int CH = Vec16<E>::N;
   const int per_row = G * (gw / CH);
   const long total = (long)T * per_row;
@@ -152,7 +153,11 @@ __global__ __launch_bounds__(256) void group_merge_add_kernel(const E* __restric
     Vec16<E>::load(h + off, a);
     Vec16<E>::load(yg + ((size_t)g * yg_rows + PAD + t) * gwp + q * CH, b);
 #pragma unroll
-    for (int j = 0; j < CH; ++j) a[j] += b[j];
+    for (int j = 0; j < CH; ++j) {
+      float v = b[j] + (bias ? bias[g * gw + q * CH + j] : 0.f);
+      if (gelu) v = gelu_f<E>(v);
+      a[j] += v;
+    }
     Vec16<E>::store(out + off, a);
   }
 }
@@ -355,14 +360,14 @@ extern "C" int sda_w2v_group_split(const void* h, void* xg, int T, int Hp, int g
 }
 
 extern "C" int sda_w2v_group_merge_add(const void* h, const void* yg, void* out, int T, int Hp, int gw, int gwp, int G,
-                                       long yg_rows, int dtype, void* stream) {
+                                       long yg_rows, const float* bias, int gelu, int dtype, void* stream) {
   const int ch = dtype == SDA_F32 ? 4 : 8;
   if (!h || !yg || !out || T < 1 || gw % ch || gwp % 64 || gw > gwp || G * gw > Hp || yg_rows < SDA_ROW_PAD + T) {
     set_error("w2v_group_merge_add: bad arguments");
     return -1;
   }
   SDA_DISPATCH(dtype, hipLaunchKernelGGL(group_merge_add_kernel<E>, dim3(grid_for((long)T * G * (gw / ch), 256)), dim3(256), 0,
-                                         (hipStream_t)stream, (const E*)h, (const E*)yg, (E*)out, T, Hp, gw, gwp, G, yg_rows));
+                                         (hipStream_t)stream, (const E*)h, (const E*)yg, (E*)out, T, Hp, gw, gwp, G, yg_rows, bias, gelu));
   return check_launch("w2v_group_merge_add");
 }
 

@@ -588,17 +588,19 @@ def clip_ranks(logits, diag, col0):
 # ---------------------------------------------------------------------------------------------------------------
 def gemm_view(x_ptr: int, w_ptr: int, y_ptr: int, *, rows: int, K: int, Cout_p: int, x_pitch: int, w_pitch: int, x_row0: int,
               x_rows_limit: int, dtype, bias=None, res_ptr: Optional[int] = None, gelu: bool = False,
-              w_rows_limit: Optional[int] = None):
+              w_rows_limit: Optional[int] = None, batch: int = 1, sample_rows: Optional[int] = None, widx=None):
     """y[x_row0 + r][0:Cout_p] = sum_k x[x_row0 + r][k] * w[co][k] (+ bias)(+ res)(GELU) for r < rows, on raw device
     addresses: conv_gemm with kernel size 1 in matrix mode.  Row r of x starts at x_ptr + (x_row0 + r) * x_pitch elements
     and is K elements long, so x_pitch < K gives overlapping rows (an im2col view of a strided Conv1d); w row co starts at
     w_ptr + co * w_pitch.  y rows have Cout_p elements.  The caller guarantees every address touched is allocated."""
     a = L.ConvArgs()
     a.x, a.w, a.bias, a.res, a.y, a.y_pre = x_ptr, w_ptr, _p(bias), res_ptr, y_ptr, None
-    a.widx, a.stats, a.partial, a.bn_x, a.bn_coef = None, None, None, None, None
-    a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = 1, rows, K, Cout_p, 1, 0
+    a.widx, a.stats, a.partial, a.bn_x, a.bn_coef = _p(widx), None, None, None, None
+    a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = batch, rows, K, Cout_p, 1, 0
     a.x_pitch, a.w_pitch = x_pitch, w_pitch
-    a.x_row0, a.x_sample_rows, a.x_rows_limit = x_row0, rows + L.ROW_PAD, x_rows_limit
+    # `batch` independent problems of `rows` rows each, `sample_rows` view rows apart (x and y alike); widx[b] picks the
+    # b-th problem's weight matrix out of w [nW][Cout_p][w_pitch]
+    a.x_row0, a.x_sample_rows, a.x_rows_limit = x_row0, (rows + L.ROW_PAD if sample_rows is None else sample_rows), x_rows_limit
     a.w_rows_limit, a.ksplit = (Cout_p if w_rows_limit is None else w_rows_limit), 1
     a.flags, a.dtype = (L.EPI_GELU if gelu else 0), dt_code(dtype)
     L.check(L.load().sda_conv_gemm(C.byref(a), _st()), "conv_gemm(view)")
@@ -621,9 +623,9 @@ def w2v_group_split(h, xg, T, gw, G, lead):
             "w2v_group_split")
 
 
-def w2v_group_merge_add(h, yg, out, T, gw, G):
+def w2v_group_merge_add(h, yg, out, T, gw, G, bias=None, gelu=False):
     L.check(L.load().sda_w2v_group_merge_add(_p(h), _p(yg), _p(out), T, h.shape[1], gw, yg.shape[2], G, yg.shape[1],
-                                             dt_code(h.dtype), _st()), "w2v_group_merge_add")
+                                             _p(bias), int(gelu), dt_code(h.dtype), _st()), "w2v_group_merge_add")
     return out
 
 

@@ -150,7 +150,8 @@ class Wav2Vec2Embedder:
         wg[:, :gw, :, :gw] = w.view(G, gw, gw, K).permute(0, 1, 3, 2)
         bg = torch.zeros(G, self.gwp, dtype=torch.float64)
         bg[:, :gw] = sd[pc + "bias"].view(G, gw)
-        P["pos.w"], P["pos.b"] = self._dev(wg.reshape(G, self.gwp, K * self.gwp), self.dtype), self._dev(bg)
+        P["pos.w"] = self._dev(wg.reshape(G, self.gwp, K * self.gwp), self.dtype)
+        P["pos.bflat"] = self._dev(sd[pc + "bias"])                     # [H]: added (with the GELU) when the groups are merged
         P["enc.g"], P["enc.be"] = self._dev(sd["encoder.layer_norm.weight"]), self._dev(sd["encoder.layer_norm.bias"])
         for i in range(cfg.num_hidden_layers):
             p, q = f"encoder.layers.{i}.", f"l{i}."
@@ -186,7 +187,9 @@ class Wav2Vec2Embedder:
                       o=rows(T, self.Hp), qk=rows(T, 2 * self.Hp), u=rows(T, self.Fp),
                       vt=torch.zeros((cfg.hidden_size, (T + 63) // 64 * 64), dtype=dt, device=dev),
                       xg=torch.zeros((G, lead + T + K + 2 * L.ROW_PAD, self.gwp), dtype=dt, device=dev),
-                      yg=torch.zeros((G, L.rows_alloc(1, T), self.gwp), dtype=dt, device=dev), lead=lead)
+                      lead=lead)
+            ws["yg"] = torch.zeros_like(ws["xg"])              # same row geometry: the G groups are ONE batched GEMM's samples
+            ws["gidx"] = torch.arange(G, dtype=torch.int32, device=dev)
             self._ws[key] = ws
         return ws
 
@@ -243,10 +246,12 @@ class Wav2Vec2Embedder:
         G, K, gw, gwp, lead = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings, self.gw, self.gwp, ws["lead"]
         xg, yg = ws["xg"], ws["yg"]
         ops.w2v_group_split(h, xg, T, gw, G, lead)
-        for g in range(G):
-            ops.gemm_view(xg[g].data_ptr(), P["pos.w"][g].data_ptr(), yg[g].data_ptr(), rows=T, K=K * gwp, Cout_p=gwp, x_pitch=gwp,
-                          w_pitch=K * gwp, x_row0=PADR, x_rows_limit=PADR + T, dtype=dt, bias=P["pos.b"][g], gelu=True)
-        h = ops.w2v_group_merge_add(h, yg, fresh(), T, gw, G)
+        # all G groups in ONE launch: the groups are the GEMM's "samples" (stride = a group's rows), widx selects the weights;
+        # bias and GELU are per group, so they move to the merge
+        grows = xg.shape[1]
+        ops.gemm_view(xg.data_ptr(), P["pos.w"].data_ptr(), yg.data_ptr(), rows=T, K=K * gwp, Cout_p=gwp, x_pitch=gwp,
+                      w_pitch=K * gwp, x_row0=PADR, x_rows_limit=G * grows, dtype=dt, batch=G, sample_rows=grows, widx=ws["gidx"])
+        h = ops.w2v_group_merge_add(h, yg, fresh(), T, gw, G, bias=P["pos.bflat"], gelu=True)
         # ---- encoder layers (HF Wav2Vec2EncoderLayerStableLayerNorm)
         states = []
         keep_from = 0 if want_all else cfg.num_hidden_layers - 3

@@ -29,7 +29,8 @@ def build(cfg_kwargs, dtype, seed=0):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("name,cfg,n", [("small", SMALL, 6000), ("small-ragged", SMALL, 3217), ("mid", MID, 30000)])
+@pytest.mark.parametrize("name,cfg,n", [("small", SMALL, 6000), ("small-ragged", SMALL, 3217), ("mid", MID, 30000),
+                                        ("small-long", SMALL, 500123)])       # 1562 frames: 25 key blocks per query block
 def test_hidden_states_match_oracle(dtype, name, cfg, n):
     W, ocfg, sd, emb = build(cfg, dtype)
     wave = torch.randn(n, generator=torch.Generator().manual_seed(1))
