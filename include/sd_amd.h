@@ -307,6 +307,10 @@ int sda_w2v_group_merge_add(const void* h, const void* yg, void* out, int T, int
  * out row layout with pitch out_pitch.  head_dim must be 64 */
 int sda_w2v_attention(const void* q, const void* k, const void* vt, void* out, int T, int heads, int head_dim,
                       long qk_pitch, long vt_pitch, long out_pitch, float scale, int dtype, void* stream);
+/* Epilogue of a split-K sda_conv_gemm (partial = its raw fp32 slabs [ksplit][T][Cp], B = 1): y[SDA_ROW_PAD + t][c] =
+ * f(sum_s partial[s][t][c] + bias[c]) + res[SDA_ROW_PAD + t][c]; bias / res may be NULL, f = GELU when `gelu` */
+int sda_splitk_epilogue(const float* partial, int ksplit, const float* bias, const void* res, void* y, int T, int Cp,
+                        int gelu, int dtype, void* stream);
 /* out fp32 dense [T][C] = mean of four row-layout hidden states (wav2vec_util.py:18-20) */
 int sda_w2v_mean4(const void* a, const void* b, const void* c, const void* d, float* out, int T, int C, int Cp,
                   int dtype, void* stream);

@@ -283,6 +283,45 @@ __global__ __launch_bounds__(256) void attention_kernel(const E* __restrict__ q,
   }
 }
 
+// Epilogue of a split-K GEMM (sda_conv_gemm with ksplit > 1 leaves raw fp32 slabs): y[PAD + t][c] =
+// f(sum_s partial[s][t][c] + bias[c]) + res[PAD + t][c], f = GELU when `gelu`; slabs summed in order (deterministic).
+// The chunks of this path are a few hundred frames: without the K split a 1024-wide Linear is 24 workgroups on 256 CUs.
+template <typename E>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ partial, int ksplit,
+                                                              const float* __restrict__ bias, const E* __restrict__ res,
+                                                              E* __restrict__ y, int T, int Cp, int gelu) {
+  constexpr int CH = Vec16<E>::N;
+  const int nch = Cp / CH;
+  const long total = (long)T * nch;
+  const size_t slab = (size_t)T * Cp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int t = (int)(i / nch), q = (int)(i - (long)t * nch);
+    float v[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) v[j] = bias ? bias[q * CH + j] : 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+      const float* p = partial + s * slab + (size_t)t * Cp + q * CH;
+#pragma unroll
+      for (int j4 = 0; j4 < CH / 4; ++j4) {
+        const float4 f = *reinterpret_cast<const float4*>(p + j4 * 4);
+        v[j4 * 4 + 0] += f.x; v[j4 * 4 + 1] += f.y; v[j4 * 4 + 2] += f.z; v[j4 * 4 + 3] += f.w;
+      }
+    }
+    if (gelu) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] = gelu_f<E>(v[j]);
+    }
+    const size_t off = (size_t)(PAD + t) * Cp + q * CH;
+    if (res) {
+      float r[CH];
+      Vec16<E>::load(res + off, r);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] += r[j];
+    }
+    Vec16<E>::store(y + off, v);
+  }
+}
+
 // out[t][c] = mean of four row-layout buffers (fp32, dense [T][C])
 template <typename E>
 __global__ void mean4_kernel(const E* __restrict__ a, const E* __restrict__ b, const E* __restrict__ c, const E* __restrict__ d,
@@ -382,6 +421,14 @@ extern "C" int sda_w2v_attention(const void* q, const void* k, const void* vt, v
   SDA_DISPATCH(dtype, hipLaunchKernelGGL(attention_kernel<E>, dim3((T + 63) / 64, heads), dim3(256), 0, (hipStream_t)stream,
                                          (const E*)q, (const E*)k, (const E*)vt, (E*)out, T, qk_pitch, vt_pitch, out_pitch, scale));
   return check_launch("w2v_attention");
+}
+
+extern "C" int sda_splitk_epilogue(const float* partial, int ksplit, const float* bias, const void* res, void* y, int T, int Cp,
+                                   int gelu, int dtype, void* stream) {
+  if (!partial || !y || ksplit < 1 || T < 1 || Cp % 64) { set_error("splitk_epilogue: bad arguments"); return -1; }
+  SDA_DISPATCH(dtype, hipLaunchKernelGGL(splitk_epilogue_kernel<E>, dim3(grid_for((long)T * (Cp / Vec16<E>::N), 256)), dim3(256), 0,
+                                         (hipStream_t)stream, partial, ksplit, bias, (const E*)res, (E*)y, T, Cp, gelu));
+  return check_launch("splitk_epilogue");
 }
 
 extern "C" int sda_w2v_mean4(const void* a, const void* b, const void* c, const void* d, float* out, int T, int C, int Cp,

@@ -84,6 +84,7 @@ SIGNATURES = {
     "sda_w2v_group_split": (i32, [vp, vp, i32, i32, i32, i32, i32, i64, i32, i32, vp]),
     "sda_w2v_group_merge_add": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i64, vp, i32, i32, vp]),
     "sda_w2v_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, f32, i32, vp]),
+    "sda_splitk_epilogue": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_w2v_mean4": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_glu_backward_colsum_og": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_gelu_backward_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

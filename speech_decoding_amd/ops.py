@@ -639,3 +639,29 @@ def w2v_mean4(a, b, c, d, T, Cc):
     out = torch.empty((T, Cc), dtype=torch.float32, device=a.device)
     L.check(L.load().sda_w2v_mean4(_p(a), _p(b), _p(c), _p(d), _p(out), T, Cc, a.shape[1], dt_code(a.dtype), _st()), "w2v_mean4")
     return out
+
+
+def linear_rows(x, w, y, T, *, bias=None, res=None, gelu=False, scratch=None):
+    """y = f(x W^T + bias) + res on ONE row-layout sample of T frames (w packed (1, 1, Cout_p, Cin_p)).  Few frames make
+    few output tiles (a 1024-wide layer at T = 299 is 24 workgroups): then the contraction is split over workgroups
+    (sda_conv_gemm's split-K slabs) and a small epilogue kernel sums the slabs and applies bias / GELU / residual."""
+    Cout_p, Cin_p = w.shape[-2], w.shape[-1]
+    tiles = ((T + 127) // 128) * (Cout_p // conv_tile_co(Cout_p, 1))
+    nslab = Cin_p // (32 if x.dtype == torch.float32 else 64)
+    ksplit = min(nslab, max(1, 256 // tiles))
+    if ksplit < 2:
+        return conv_gemm(x, w, y, B=1, T=T, KS=1, dil=0, bias=bias, res=res, gelu=gelu)
+    need = ksplit * T * Cout_p
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty(need, dtype=torch.float32, device=x.device)
+    a = L.ConvArgs()
+    a.x, a.w, a.bias, a.res, a.y, a.y_pre, a.widx, a.stats = _p(x), _p(w), None, None, None, None, None, None
+    a.partial, a.bn_x, a.bn_coef = _p(scratch), None, None
+    a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = 1, T, Cin_p, Cout_p, 1, 0
+    a.x_pitch, a.w_pitch = x.shape[1], Cin_p
+    a.x_row0, a.x_sample_rows, a.x_rows_limit = L.ROW_PAD, L.rows_tp(T), x.shape[0]
+    a.w_rows_limit, a.ksplit, a.flags, a.dtype = Cout_p, ksplit, 0, dt_code(x.dtype)
+    L.check(L.load().sda_conv_gemm(C.byref(a), _st()), "conv_gemm(split-K)")
+    L.check(L.load().sda_splitk_epilogue(_p(scratch), ksplit, _p(bias), _p(res), _p(y), T, Cout_p, int(gelu), dt_code(x.dtype), _st()),
+            "splitk_epilogue")
+    return y

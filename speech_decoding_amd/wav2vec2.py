@@ -189,6 +189,7 @@ class Wav2Vec2Embedder:
                       xg=torch.zeros((G, lead + T + K + 2 * L.ROW_PAD, self.gwp), dtype=dt, device=dev),
                       lead=lead)
             ws["yg"] = torch.zeros_like(ws["xg"])              # same row geometry: the G groups are ONE batched GEMM's samples
+            ws["partial"] = torch.empty(64 * T * max(2 * self.Hp, self.Fp) // 8 + 1, dtype=torch.float32, device=dev)
             ws["gidx"] = torch.arange(G, dtype=torch.int32, device=dev)
             self._ws[key] = ws
         return ws
@@ -239,7 +240,8 @@ class Wav2Vec2Embedder:
             b = pool[nxt[0] % len(pool)]
             nxt[0] += 1
             return b
-        h = ops.conv_gemm(f[-1], P["fp.w"], fresh(), B=1, T=T, KS=1, dil=0, bias=P["fp.b"])
+        part = ws["partial"]
+        h = ops.linear_rows(f[-1], P["fp.w"], fresh(), T, bias=P["fp.b"], scratch=part)
         if self.taps is not None:
             self.taps["proj"] = self._copy_out(h, T)
         # ---- positional conv embedding: h = h + GELU(conv(h))
@@ -262,15 +264,15 @@ class Wav2Vec2Embedder:
             if i >= keep_from:
                 states.append(self._copy_out(h, T) if want_all else h)
             ops.layernorm_rows(h, a, P[q + "ln1.g"], P[q + "ln1.be"], T, H, cfg.layer_norm_eps)
-            ops.conv_gemm(a, P[q + "qk.w"], qk, B=1, T=T, KS=1, dil=0, bias=P[q + "qk.b"])
+            ops.linear_rows(a, P[q + "qk.w"], qk, T, bias=P[q + "qk.b"], scratch=part)
             # V^T [H][Tp] = W_v [H][Hp] . a^T: the weights are the GEMM's rows, the activations (frames PAD .. PAD + Tp) its columns
             ops.gemm_view(P[q + "v.w"].data_ptr(), a.data_ptr() + PADR * Hp * es, vt.data_ptr(), rows=H, K=Hp, Cout_p=Tp, x_pitch=Hp,
                           w_pitch=Hp, x_row0=0, x_rows_limit=H, dtype=dt)
             ops.w2v_attention(qk.data_ptr(), qk.data_ptr() + Hp * es, vt, o, T, heads, 64, 2 * Hp, 64 ** -0.5)
-            h_mid = ops.conv_gemm(o, P[q + "o.w"], fresh(), B=1, T=T, KS=1, dil=0, bias=P[q + "o.b"], res=h)
+            h_mid = ops.linear_rows(o, P[q + "o.w"], fresh(), T, bias=P[q + "o.b"], res=h, scratch=part)
             ops.layernorm_rows(h_mid, a, P[q + "ln2.g"], P[q + "ln2.be"], T, H, cfg.layer_norm_eps)
-            ops.conv_gemm(a, P[q + "f1.w"], u, B=1, T=T, KS=1, dil=0, bias=P[q + "f1.b"], gelu=True)
-            h = ops.conv_gemm(u, P[q + "f2.w"], fresh(), B=1, T=T, KS=1, dil=0, bias=P[q + "f2.b"], res=h_mid)
+            ops.linear_rows(a, P[q + "f1.w"], u, T, bias=P[q + "f1.b"], gelu=True, scratch=part)
+            h = ops.linear_rows(u, P[q + "f2.w"], fresh(), T, bias=P[q + "f2.b"], res=h_mid, scratch=part)
         last = ops.layernorm_rows(h, fresh(), P["enc.g"], P["enc.be"], T, H, cfg.layer_norm_eps)
         states.append(self._copy_out(last, T) if want_all else last)
         return T, states
