@@ -95,6 +95,8 @@ class EncoderEngine:
         self.forward_pair_tiles = True       # forward k = 3 convs (nothing competes for the CU's LDS there): two
                                              # tiles per workgroup share each weight slab — fewer LDS-DMA bytes per FLOP
         self.flat_tiles_forward = True       # k = 3 convs on the 256-row flat-tile kernel (conv3_flat.hip) where it applies
+        self.flat_tile_options = 0           # extra conv3_flat flags: 1024 = co-resident workgroups take their tiles in opposite
+                                             # order, 64 = static priority for one workgroup of each pair
         self.fuse_glu_forward = True         # F.glu in conv2's epilogue (flat-tile kernel, D2p % 80 == 0): no [value | gate] buffer
         self.compose_subject_block = True    # SpatialAttention, the shared 1x1 conv and the per-subject 1x1 conv as ONE per-subject
                                              # matrix (needs a spare padding channel for the folded bias: C < Cp)
@@ -283,7 +285,7 @@ class EncoderEngine:
                 ctx.packed_T = bwd_plan.run(P)
         k3_flags = L.CONV_PAIR_TILES if self.forward_pair_tiles else 0
         if self.flat_tiles_forward:
-            k3_flags |= L.CONV_FLAT_TILES
+            k3_flags |= L.CONV_FLAT_TILES | self.flat_tile_options
 
         # ---- SubjectBlock (models.py:111-117)
         composed = self.composed
