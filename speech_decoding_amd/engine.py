@@ -98,6 +98,8 @@ class EncoderEngine:
         self.flat_tile_options = 0           # extra conv3_flat flags: 1024 = co-resident workgroups take their tiles in opposite
                                              # order, 64 = static priority for one workgroup of each pair
         self.fuse_glu_forward = True         # F.glu in conv2's epilogue (flat-tile kernel, D2p % 80 == 0): no [value | gate] buffer
+        self.skip_x0_gradient = True         # composed SubjectBlock: its weight gradient straight from block 0's dh0 and X (kernel-3
+                                             # per-subject weight gradient + chain rule) instead of conv0's data gradient + dx0 (x) X
         self.compose_subject_block = True    # SpatialAttention, the shared 1x1 conv and the per-subject 1x1 conv as ONE per-subject
                                              # matrix (needs a spare padding channel for the folded bias: C < Cp)
         # backward keeps the 128-row tile kernel (40 KB of LDS per workgroup): the flat kernel's two 76 KB workgroups fill a
@@ -251,8 +253,10 @@ class EncoderEngine:
             # with few (S = 1 in configs 1/4) every subject's samples are cut into r slices so that the launch still
             # has ~wgrad_target_wgs workgroups, and the r slabs of a subject are summed afterwards in fixed order.
             tile_m = 160 if d.D1p % 160 == 0 else (128 if d.D1p % 128 == 0 else 64)
-            cin_p = d.Cp if self.composed else d.D1p       # (composed SubjectBlock: the gradient of the (D1, C) per-subject matrix)
-            ntiles = (d.D1p // tile_m) * (cin_p // (128 if cin_p % 128 == 0 else 64))
+            ntiles = (d.D1p // tile_m) * (d.D1p // (128 if d.D1p % 128 == 0 else 64))
+            if self.composed:       # the per-subject gradient is the k = 3 one of (block 0's dh0, X): D2p x 64-channel tiles
+                tm = 160 if d.D2p % 160 == 0 else (128 if d.D2p % 128 == 0 else 64)
+                ntiles = (d.D2p // tm) * (d.Cp // 64)
             r = int(max(1, min(max(1, B // max(1, d.S)), round(self.wgrad_target_wgs / max(1, ntiles * d.S)))))
             perm, seg = subject_segments(sidx, d.S, r)
             ctx.subj_perm = up("subj_perm", perm, dev)
@@ -552,8 +556,13 @@ class EncoderEngine:
                 grads[f"b{k}.c{j}b"] = null_bias[2 * k + j] if ctx.training else bias_grad(ops.colsum(dh, B, T, scratch), d.D2)
                 res = dh if (j == 1 or k > 0) else None
                 out = tmp("da", d.D2p) if j == 1 else tmp("dxB" if flip == 0 else "dxA", ci_p)
-                da1, tstats = dgrad(dh, f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res,
-                                    bn=(bufs[f"b{k}.h0"], ctx.bn[f"b{k}.bn0"][2]) if j == 1 else None)
+                if k == 0 and j == 0 and ctx.composed is not None and self.skip_x0_gradient:
+                    # the composed SubjectBlock takes its weight gradient straight from dh0 and X (below): the gradient with
+                    # respect to x0 is never needed, this data-gradient conv is not run
+                    da1, tstats, dh0 = None, None, dh
+                else:
+                    da1, tstats = dgrad(dh, f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res,
+                                        bn=(bufs[f"b{k}.h0"], ctx.bn[f"b{k}.bn0"][2]) if j == 1 else None)
                 grads[f"b{k}.c{j}w"] = wgrad(dh, src, 3, dil[j], d.D2, ci)
             dx = da1
             flip ^= 1
@@ -572,11 +581,24 @@ class EncoderEngine:
         if ctx.composed is not None:
             Wd, T1aug, Ws = ctx.composed
             r = ctx.subj_slices
-            slabs = ops.wgrad_gemm(dhs, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg,
-                                   nseg=r * d.S)                        # (r*S, 1, D1p, Cp): dL/dW_tot[s], column C = dL/db_tot[s]
-            if r > 1:
-                slabs = ops.reduce_slabs(slabs.view(r, -1))
-            G = slabs.view(d.S, d.D1p, d.Cp)[:, : d.D1, : d.C + 1]                            # (S, D1, C + 1)
+            # x0 = W_tot[s] X feeds block 0's conv0 and nothing else, and h0 = sum_tap W0[tap] x0[t + (tap - 1) dil], so
+            #   dL/dW_tot[s] = sum_tap W0[tap]^T M[s][tap],   M[s][tap] = sum_{b in s, t} dh0[b, t] (x) X[b, t + (tap - 1) dil]
+            # = the per-subject kernel-3 weight gradient of (dh0, X) followed by one batched (D1 x 3 D2) . (3 D2 x C+1) product:
+            # neither conv0's data gradient (a 320 -> 320 kernel-3 conv) nor a weight gradient over dx0 is computed.
+            if self.skip_x0_gradient:
+                M = ops.wgrad_gemm(dh0, bufs["Xt"], B=B, T=T, KS=3, dil=block_dilations(0)[0], perm=ctx.subj_perm,
+                                   seg_start=ctx.subj_seg, nseg=r * d.S)     # (r*S, 3, D2p, Cp); column C: the folded bias
+                if r > 1:
+                    M = ops.reduce_slabs(M.view(r, -1))
+                W0cat = torch.zeros((d.D1, 3, d.D2p), dtype=torch.float32, device=dev)
+                W0cat[:, :, : d.D2] = P["b0.c0w"].permute(1, 2, 0)                                 # [d][tap][o]
+                G = torch.matmul(W0cat.view(d.D1, 3 * d.D2p), M.view(d.S, 3 * d.D2p, d.Cp))[:, :, : d.C + 1]   # (S, D1, C + 1)
+            else:
+                slabs = ops.wgrad_gemm(dhs, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg,
+                                       nseg=r * d.S)                    # (r*S, 1, D1p, Cp): dL/dW_tot[s], column C = dL/db_tot[s]
+                if r > 1:
+                    slabs = ops.reduce_slabs(slabs.view(r, -1))
+                G = slabs.view(d.S, d.D1p, d.Cp)[:, : d.D1, : d.C + 1]                            # (S, D1, C + 1)
             grads["subj_w"] = torch.matmul(G, T1aug.t()).unsqueeze(-1)                         # W_tot = W_subj T1aug
             dT1 = Ws.permute(2, 0, 1).reshape(d.D1, d.S * d.D1) @ G.reshape(d.S * d.D1, d.C + 1)   # sum_s W_subj[s]^T G[s]
             grads["sb_b"] = dT1[:, d.C].contiguous()
