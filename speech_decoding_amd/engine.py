@@ -275,8 +275,14 @@ class EncoderEngine:
             ev = torch.cuda.Event()
             ev.record(main)                      # the optimiser's update of P is on the main stream
             side.wait_event(ev)
+            composed = self.composed
+            Xt = rows("Xt", d.Cp)
             with torch.cuda.stream(side):
                 pk.update(fwd_plan.run(P))
+                # the input's layout change rides on the same stream: the main stream meanwhile computes the SpatialAttention
+                # weights and composes the SubjectBlock matrices (parameter-sized work that needs neither)
+                ops.pack_rows(X, Xt, ones_channel=d.C if composed else None)
+                X.record_stream(side)
                 packed_ready = torch.cuda.Event()
                 packed_ready.record(side)
                 if need_grad:
@@ -287,14 +293,14 @@ class EncoderEngine:
             pk.update(fwd_plan.run(P))
             if need_grad:
                 ctx.packed_T = bwd_plan.run(P)
+            composed = self.composed
+            Xt = rows("Xt", d.Cp)
+            ops.pack_rows(X, Xt, ones_channel=d.C if composed else None)
         k3_flags = L.CONV_PAIR_TILES if self.forward_pair_tiles else 0
         if self.flat_tiles_forward:
             k3_flags |= L.CONV_FLAT_TILES | self.flat_tile_options
 
         # ---- SubjectBlock (models.py:111-117)
-        composed = self.composed
-        Xt = rows("Xt", d.Cp)
-        ops.pack_rows(X, Xt, ones_channel=d.C if composed else None)
         bufs["Xt"] = Xt
         W_sa, Wp = ops.sa_weights_forward(P["z"], P["cos"], P["sin"], mask, d.D1p, d.Cp, dt, fwd_table=P.get("sa_tab_f"))
         ctx.W_sa = W_sa
@@ -313,16 +319,16 @@ class EncoderEngine:
             Wtot[:, 0, : d.D1, : d.C + 1].copy_(torch.matmul(Ws, T1aug))
             if need_grad:
                 ctx.composed = (Wd, T1aug, Ws)
+            if packed_ready is not None:
+                self._wait("packed operands (forward)", main, packed_ready)
             x = ops.conv_gemm(Xt, Wtot, rows("x0", d.D1p), B=B, T=T, KS=1, dil=0, widx=ctx.widx,
                               alg_dims=(d.C, d.D1))
             bufs["x0"] = x
+        else:
             if packed_ready is not None:
                 self._wait("packed operands (forward)", main, packed_ready)
-        else:
             h_sa = ops.conv_gemm(Xt, Wp, rows("h_sa", d.D1p), B=B, T=T, KS=1, dil=0, alg_dims=(d.C, d.D1))
             bufs["h_sa"] = h_sa
-            if packed_ready is not None:
-                self._wait("packed operands (forward)", main, packed_ready)
             h_c = ops.conv_gemm(h_sa, pk["sb_w"], rows("h_c", d.D1p), B=B, T=T, KS=1, dil=0, bias=pk["sb_b"],
                                 alg_dims=(d.D1, d.D1))
             bufs["h_c"] = h_c
