@@ -316,7 +316,8 @@ class EncoderEngine:
             Wtot = self._const.get(key)
             if Wtot is None:
                 Wtot = self._const[key] = torch.zeros((d.S, 1, d.D1p, d.Cp), dtype=dt, device=dev)
-            Wtot[:, 0, : d.D1, : d.C + 1].copy_(torch.matmul(Ws, T1aug))
+            # (all subjects in ONE (S D1 x D1) . (D1 x C+1) product: the batched form picks a much slower library kernel)
+            Wtot[:, 0, : d.D1, : d.C + 1].copy_((Ws.reshape(d.S * d.D1, d.D1) @ T1aug).view(d.S, d.D1, d.C + 1))
             if need_grad:
                 ctx.composed = (Wd, T1aug, Ws)
             if packed_ready is not None:
@@ -605,8 +606,9 @@ class EncoderEngine:
                 if r > 1:
                     slabs = ops.reduce_slabs(slabs.view(r, -1))
                 G = slabs.view(d.S, d.D1p, d.Cp)[:, : d.D1, : d.C + 1]                            # (S, D1, C + 1)
-            grads["subj_w"] = torch.matmul(G, T1aug.t()).unsqueeze(-1)                         # W_tot = W_subj T1aug
-            dT1 = Ws.permute(2, 0, 1).reshape(d.D1, d.S * d.D1) @ G.reshape(d.S * d.D1, d.C + 1)   # sum_s W_subj[s]^T G[s]
+            G2 = G.reshape(d.S * d.D1, d.C + 1)            # (one 2-D product each instead of S small ones: see forward)
+            grads["subj_w"] = (G2 @ T1aug.t()).view(d.S, d.D1, d.D1, 1)                        # W_tot = W_subj T1aug
+            dT1 = Ws.reshape(d.S * d.D1, d.D1).t() @ G2                                          # sum_s W_subj[s]^T G[s]
             grads["sb_b"] = dT1[:, d.C].contiguous()
             dT1 = dT1[:, : d.C]
             grads["sb_w"] = (dT1 @ Wd.t()).unsqueeze(-1)
