@@ -98,6 +98,8 @@ class EncoderEngine:
         self.flat_tile_options = 0           # extra conv3_flat flags: 1024 = co-resident workgroups take their tiles in opposite
                                              # order, 64 = static priority for one workgroup of each pair
         self.fuse_glu_forward = True         # F.glu in conv2's epilogue (flat-tile kernel, D2p % 80 == 0): no [value | gate] buffer
+        self.chain_rule_bf16 = False         # 16-bit modes: the chain rule's parameter-space products on bf16 operands (see _mm);
+                                             # measured: no gain in the step (7.64 vs 7.59 ms), so the fp32 products stay
         self.skip_x0_gradient = True         # composed SubjectBlock: its weight gradient straight from block 0's dh0 and X (kernel-3
                                              # per-subject weight gradient + chain rule) instead of conv0's data gradient + dx0 (x) X
         self.compose_subject_block = True    # SpatialAttention, the shared 1x1 conv and the per-subject 1x1 conv as ONE per-subject
@@ -170,6 +172,14 @@ class EncoderEngine:
     @property
     def glu_fused(self) -> bool:
         return bool(self.fuse_glu_forward and self.flat_tiles_forward and self.d.D2p % 80 == 0)
+
+    def _mm(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """Parameter-space product of the composed SubjectBlock's chain rule.  fp32 mode: fp32 (the exact path).  16-bit modes:
+        optionally (chain_rule_bf16) bf16 operands with fp32 accumulation, like every other weight gradient of those modes — the fp32
+        library GEMMs of these shapes run at ~30 TFLOP/s on the step's tail, but the step did not get shorter without them."""
+        if self.dtype == torch.float32 or not self.chain_rule_bf16:
+            return a @ b
+        return (a.to(torch.bfloat16) @ b.to(torch.bfloat16)).float()
 
     def _wait(self, label: str, stream, event):
         """stream.wait_event(event); with a probe attached, bracketed by timing events (how long the stream sat idle)."""
@@ -599,7 +609,7 @@ class EncoderEngine:
                     M = ops.reduce_slabs(M.view(r, -1))
                 W0cat = torch.zeros((d.D1, 3, d.D2p), dtype=torch.float32, device=dev)
                 W0cat[:, :, : d.D2] = P["b0.c0w"].permute(1, 2, 0)                                 # [d][tap][o]
-                G = torch.matmul(W0cat.view(d.D1, 3 * d.D2p), M.view(d.S, 3 * d.D2p, d.Cp))[:, :, : d.C + 1]   # (S, D1, C + 1)
+                G = self._mm(W0cat.view(d.D1, 3 * d.D2p), M.view(d.S, 3 * d.D2p, d.Cp))[:, :, : d.C + 1]        # (S, D1, C + 1)
             else:
                 slabs = ops.wgrad_gemm(dhs, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg,
                                        nseg=r * d.S)                    # (r*S, 1, D1p, Cp): dL/dW_tot[s], column C = dL/db_tot[s]
@@ -607,8 +617,8 @@ class EncoderEngine:
                     slabs = ops.reduce_slabs(slabs.view(r, -1))
                 G = slabs.view(d.S, d.D1p, d.Cp)[:, : d.D1, : d.C + 1]                            # (S, D1, C + 1)
             G2 = G.reshape(d.S * d.D1, d.C + 1)            # (one 2-D product each instead of S small ones: see forward)
-            grads["subj_w"] = (G2 @ T1aug.t()).view(d.S, d.D1, d.D1, 1)                        # W_tot = W_subj T1aug
-            dT1 = Ws.reshape(d.S * d.D1, d.D1).t() @ G2                                          # sum_s W_subj[s]^T G[s]
+            grads["subj_w"] = self._mm(G2, T1aug.t()).view(d.S, d.D1, d.D1, 1)                 # W_tot = W_subj T1aug
+            dT1 = self._mm(Ws.reshape(d.S * d.D1, d.D1).t(), G2)                                 # sum_s W_subj[s]^T G[s]
             grads["sb_b"] = dT1[:, d.C].contiguous()
             dT1 = dT1[:, : d.C]
             grads["sb_w"] = (dT1 @ Wd.t()).unsqueeze(-1)

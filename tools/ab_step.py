@@ -63,6 +63,8 @@ for k, v in variants.items():           # warm-up of every variant (workspaces, 
     with torch.cuda.stream(streams[eng.main_priority]):
         for _ in range(3): step()
     torch.cuda.synchronize()
+import gc
+gc.collect(); gc.freeze()               # (a generation-2 collection inside a timed round is worth 80 ms)
 for r in range(rounds):
     for k, v in variants.items():
         apply(v)
