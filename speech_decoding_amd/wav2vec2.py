@@ -93,6 +93,10 @@ class Wav2Vec2Embedder:
         # A chunk is ~260 small launches (frames, not batch, are the GEMMs' rows): launch-bound from Python.  The chunk
         # lengths np.array_split produces differ by at most one sample, so one or two HIP graphs replay all ten chunks.
         self.use_graphs = True
+        # ... and the chunks are independent: `streams_in_flight` of them run at a time on HIP streams of their own (each with
+        # its own buffers and graphs), so one chunk's 24-workgroup GEMMs share the chip with the others'
+        self.streams_in_flight = 4
+        self._streams: List[torch.cuda.Stream] = []
         self._pack({k: v.detach().to(torch.float64).cpu() for k, v in state_dict.items() if v.is_floating_point()})
 
     @classmethod
@@ -173,11 +177,11 @@ class Wav2Vec2Embedder:
         self.P = P
 
     # ------------------------------------------------------------------ workspace (per frame count)
-    def _workspace(self, T: int, frames: List[int]) -> dict:
-        key = (T, tuple(frames))
+    def _workspace(self, T: int, frames: List[int], slot: int = 0) -> dict:
+        key = (T, tuple(frames), slot)
         ws = self._ws.get(key)
         if ws is None:
-            if len(self._ws) >= 4:
+            if len(self._ws) >= 4 * max(1, self.streams_in_flight):
                 self._ws.clear()
             cfg, dt, dev = self.cfg, self.dtype, self.device
             rows = lambda t, c: ops.new_rows(1, t, c, dt, dev)
@@ -189,7 +193,8 @@ class Wav2Vec2Embedder:
                       xg=torch.zeros((G, lead + T + K + 2 * L.ROW_PAD, self.gwp), dtype=dt, device=dev),
                       lead=lead)
             ws["yg"] = torch.zeros_like(ws["xg"])              # same row geometry: the G groups are ONE batched GEMM's samples
-            ws["partial"] = torch.empty(64 * T * max(2 * self.Hp, self.Fp) // 8 + 1, dtype=torch.float32, device=dev)
+            # split-K scratch of ops.linear_rows: ksplit * T * Cout_p <= (256 / tiles) * T * Cout_p ~ 256 * 128 * 160 floats
+            ws["partial"] = torch.empty(2 * 256 * 128 * 160, dtype=torch.float32, device=dev)
             ws["gidx"] = torch.arange(G, dtype=torch.int32, device=dev)
             self._ws[key] = ws
         return ws
@@ -202,7 +207,7 @@ class Wav2Vec2Embedder:
         return self
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, wave: torch.Tensor, want_all: bool):
+    def _forward(self, wave: torch.Tensor, want_all: bool, slot: int = 0):
         """wave: 1-D fp32 on the device.  Returns (T, [row-layout hidden states kept]) — all of them when want_all (then each
         is copied out), otherwise the last four."""
         cfg, P, dt, es = self.cfg, self.P, self.dtype, self.es
@@ -214,7 +219,7 @@ class Wav2Vec2Embedder:
         T = frames[-1]
         if T < 1:
             raise ValueError(f"waveform of {n} samples is shorter than the feature encoder's receptive field")
-        ws = self._workspace(T, frames)
+        ws = self._workspace(T, frames, slot)
         Cp, Hp, PADR = self.Cp, self.Hp, L.ROW_PAD
         C0, H = cfg.conv_dim[0], cfg.hidden_size
         # ---- feature encoder (HF Wav2Vec2FeatureEncoder, layer-norm conv layers)
@@ -286,32 +291,33 @@ class Wav2Vec2Embedder:
         """All `output_hidden_states` of the model for one 1-D waveform: num_hidden_layers + 1 tensors (T, H), fp32."""
         return self._forward(self._wave(wave), True)[1]
 
-    def _last_four_eager(self, wave: torch.Tensor) -> torch.Tensor:
-        T, st = self._forward(wave, False)
+    def _last_four_eager(self, wave: torch.Tensor, slot: int = 0) -> torch.Tensor:
+        T, st = self._forward(wave, False, slot)
         return ops.w2v_mean4(st[0], st[1], st[2], st[3], T, self.cfg.hidden_size)
 
     @torch.no_grad()
-    def last_four_mean(self, wave: torch.Tensor) -> torch.Tensor:
-        """`_process_chunk` (wav2vec_util.py:15-20): mean of hidden_states[-4:], (T, H) fp32."""
+    def last_four_mean(self, wave: torch.Tensor, slot: int = 0) -> torch.Tensor:
+        """`_process_chunk` (wav2vec_util.py:15-20): mean of hidden_states[-4:], (T, H) fp32.  Runs on the current stream with
+        buffer set `slot` (concurrent chunks need different slots)."""
         wave = self._wave(wave)
         if not self.use_graphs or self.taps is not None:
-            return self._last_four_eager(wave)
+            return self._last_four_eager(wave, slot)
         n = wave.numel()
         frames, t = [], n
         for k, s in zip(self.cfg.conv_kernel, self.cfg.conv_stride):
             t = (t - k) // s + 1
             frames.append(t)
         if frames[-1] < 1:
-            return self._last_four_eager(wave)           # raises the length error
-        graphs = self._workspace(frames[-1], frames).setdefault("graphs", {})      # a graph lives and dies with its buffers
+            return self._last_four_eager(wave, slot)     # raises the length error
+        graphs = self._workspace(frames[-1], frames, slot).setdefault("graphs", {})      # a graph lives and dies with its buffers
         entry = graphs.get(n)
         if entry is None:
             static_in = wave.clone()
-            self._last_four_eager(static_in)              # warm-up outside the capture (first-use allocations, lazy loads)
+            self._last_four_eager(static_in, slot)        # warm-up outside the capture (first-use allocations, lazy loads)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_out = self._last_four_eager(static_in)
+                static_out = self._last_four_eager(static_in, slot)
             if len(graphs) >= 4:
                 graphs.clear()
             entry = graphs[n] = (graph, static_in, static_out)
@@ -331,7 +337,29 @@ class Wav2Vec2Embedder:
         if waveform.dim() != 2:
             raise ValueError("expected a (1, L) waveform")
         wave = self._wave(waveform[0])
-        out = [self.last_four_mean(wave[a:b]) for a, b in chunk_bounds(wave.numel(), n_chunks)]
+        bounds = chunk_bounds(wave.numel(), n_chunks)
+        n = max(1, min(self.streams_in_flight, len(bounds)))
+        if n == 1 or self.taps is not None:
+            return torch.vstack([self.last_four_mean(wave[a:b]) for a, b in bounds]).t()
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        out = []
+        for i, (a, b) in enumerate(bounds):
+            st = self._streams[i % n]
+            if i < n:
+                st.wait_event(ready)                     # the waveform was produced on the caller's stream
+                wave.record_stream(st)
+            with torch.cuda.stream(st):
+                out.append(self.last_four_mean(wave[a:b], slot=i % n))
+        for st in self._streams[:n]:
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
+        for o in out:
+            o.record_stream(main)
         return torch.vstack(out).t()
 
     __call__ = embed
