@@ -36,6 +36,11 @@ enum { SDA_F32 = 0, SDA_BF16 = 1, SDA_F16 = 2 };   /* storage + MFMA operand typ
 
 /* conv_gemm epilogue flags */
 enum { SDA_EPI_GELU = 1,
+       SDA_EPI_GLU_BWD = 4,         /* the conv's output is the gradient dy entering an F.glu whose forward kept (out, gate) (SDA_EPI_GLU):
+                                       y [rows][2 * Cout_p] = [dy * sig(gate) | dy * out * (1 - sig(gate))] (the GLU backward, written
+                                       instead of dy), `stats` rows = per-tile column sums of the two halves ([tile][0] value half,
+                                       [tile][1] gate half: the bias gradient of the conv that fed the GLU).  Needs glu_out, glu_gate and
+                                       stats; the tile-per-workgroup kernels only (not SDA_CONV_FLAT_TILES); no GELU / bn_x */
        SDA_EPI_GLU = 2,             /* with SDA_CONV_FLAT_TILES: the conv's Cout_p = 2 * Hp channels are [value | gate] pairs
                                        laid out per 160-channel tile as 80 value + 80 gate channels (weights and bias packed with
                                        glu_tile = 80); y [rows][Hp] = value * sigmoid(gate) (models.py:164, F.glu), both as
@@ -132,6 +137,8 @@ typedef struct sda_conv_args {
                          * BatchNorm backward instead: [tile][0][c] = sum dg, [tile][1][c] = sum dg * xhat, with
                          * dg = y * GELU'(gamma * xhat + beta), xhat = (bn_x - mean) * rstd, y as stored */
   const float* bn_coef; /* with bn_x: [4][Cout_p] = gamma, beta, mean, rstd (zero on padded channels) */
+  const void* glu_out;  /* with SDA_EPI_GLU_BWD: RL [rows][Cout_p] forward output of the GLU (value * sigmoid(gate)) ... */
+  const void* glu_gate; /* ... and its gate, RL [rows][Cout_p] */
   int B, T, Cin_p, Cout_p, KS, dil;
   long x_pitch, w_pitch; /* elements per row of x / per output-channel row of w.  With KS == 1, x_pitch < Cin_p is allowed:
                           * rows then overlap — a frame-major buffer read with pitch stride*C and row length k*C is the

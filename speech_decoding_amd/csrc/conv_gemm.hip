@@ -373,6 +373,28 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
 #pragma unroll
             for (int j = 0; j < CH; ++j) v[j] = gelu_f<E>(v[j]);
           }
+          if constexpr (!BN) {
+            if (a.flags & SDA_EPI_GLU_BWD) {
+              // v = the gradient entering F.glu (models.py:164): write the GLU backward instead of it (what bwd_colsum_kernel<E, 2>
+              // does in a pass of its own, from dy as STORED: here dy never goes to memory) and keep the column sums of the two
+              // halves in the statistics slots (the bias gradient of the conv that fed the GLU)
+              float o8[CH], g8[CH], dg8[CH];
+              Vec16<E>::load(reinterpret_cast<const E*>(a.glu_out) + off, o8);
+              Vec16<E>::load(reinterpret_cast<const E*>(a.glu_gate) + off, g8);
+#pragma unroll
+              for (int j = 0; j < CH; ++j) {
+                const float sg = sigmoid_f(g8[j]);
+                dg8[j] = v[j] * o8[j] * (1.f - sg);
+                v[j] *= sg;
+                ssum[j] += Vec16<E>::round(v[j]);
+                ssq[j] += Vec16<E>::round(dg8[j]);
+              }
+              const size_t off2 = (size_t)(out_row0 + h * EP_ROWS + row) * (2 * a.Cout_p) + co0 + chunk * CH;
+              Vec16<E>::store(yg + off2, v);
+              Vec16<E>::store(yg + off2 + a.Cout_p, dg8);
+              continue;
+            }
+          }
           Vec16<E>::store(yg + off, v);
           if constexpr (BN) {
             // BatchNorm+GELU backward sums of the layer this gradient enters (what col_reduce_kernel<E, 1>
@@ -497,6 +519,10 @@ extern "C" int sda_conv_gemm(const sda_conv_args* a, void* stream) {
   if (a->ksplit < 1 || (a->ksplit > 1 && (!a->partial || a->B != 1))) { set_error("conv_gemm: split-K needs partial output and B == 1"); return -1; }
   if (a->partial && a->ksplit < 1) { set_error("conv_gemm: bad ksplit"); return -1; }
   if (a->B < 1 || a->T < 1) { set_error("conv_gemm: empty batch"); return -1; }
+  if ((a->flags & SDA_EPI_GLU_BWD) && (!a->glu_out || !a->glu_gate || !a->stats || a->bn_x || a->partial || a->y_pre ||
+                                     (a->flags & (SDA_EPI_GELU | SDA_EPI_GLU | SDA_CONV_FLAT_TILES)))) {
+    set_error("conv_gemm: SDA_EPI_GLU_BWD needs glu_out, glu_gate and stats, and excludes bn_x / GELU / flat tiles / split-K"); return -1;
+  }
   if (a->bn_x && (!a->bn_coef || !a->stats || a->partial || (a->flags & SDA_EPI_GELU))) {
     set_error("conv_gemm: bn_x needs bn_coef and stats, and excludes split-K / GELU epilogues"); return -1;
   }

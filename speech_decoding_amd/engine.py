@@ -98,6 +98,10 @@ class EncoderEngine:
         self.flat_tile_options = 0           # extra conv3_flat flags: 1024 = co-resident workgroups take their tiles in opposite
                                              # order, 64 = static priority for one workgroup of each pair
         self.fuse_glu_forward = True         # F.glu in conv2's epilogue (flat-tile kernel, D2p % 80 == 0): no [value | gate] buffer
+        self.fuse_glu_backward = False       # the GLU backward in the epilogue of the conv that produces its incoming gradient
+                                             # (needs the fused forward: bufs hold (out, gate)); not with flat-tile data gradients.
+                                             # Off: measured 7.87 vs 7.77 ms — the separate pass is HBM-bound and runs beside the
+                                             # weight-gradient stream's MFMA work for free, the heavier conv epilogue does not
         self.chain_rule_bf16 = False         # 16-bit modes: the chain rule's parameter-space products on bf16 operands (see _mm);
                                              # measured: no gain in the step (7.64 vs 7.59 ms), so the fp32 products stay
         self.skip_x0_gradient = True         # composed SubjectBlock: its weight gradient straight from block 0's dh0 and X (kernel-3
@@ -499,11 +503,18 @@ class EncoderEngine:
 
         ntile = B * ops.n_t_tiles(T)
 
-        def dgrad(dy, key, w_fp32, Cout_p, Cin_p, out, KS, dil, res=None, widx=None, bn=None, **glu):
+        def dgrad(dy, key, w_fp32, Cout_p, Cin_p, out, KS, dil, res=None, widx=None, bn=None, glu_bwd=None, **glu):
             """Data-gradient conv.  bn = (h, coef): `out` is the gradient entering GELU(BN(h)); the conv's epilogue
             then also emits the per-tile BatchNorm-backward sums (returned as second value) — the separate
-            reduction pass over (out, h) is not needed."""
+            reduction pass over (out, h) is not needed.  glu_bwd = (x_out, gate) of the block BELOW: the conv's output is
+            the gradient entering that block's F.glu, and the epilogue writes the GLU backward [d value | d gate] into `out`
+            (twice as wide) plus the per-tile column sums of both halves (second value) instead of the gradient itself."""
             bflags = (L.CONV_FLAT_TILES | (L.CONV_ONE_PER_CU if self.flat_backward_one_per_cu else 0)) if (self.flat_tiles_backward and KS == 3) else 0
+            if glu_bwd is not None:
+                st = torch.empty((ops.conv_stats_rows(B, T, KS, Cin_p, 0), 2, Cin_p), dtype=torch.float32, device=dev)
+                ops.conv_gemm(dy, ctx.packed_T[key], out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx, stats=st, glu_bwd=glu_bwd,
+                              alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]))
+                return out, st
             if bn is None or not self.fuse_bn_backward_stats or bn[1] is None:
                 return ops.conv_gemm(dy, ctx.packed_T[key], out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx,
                                      alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]), flags=bflags), None
@@ -528,7 +539,16 @@ class EncoderEngine:
         du1 = tmp("du1", d.F1p)
         cs = ops.gelu_backward_colsum(bufs["u1"], dg1, du1, B, T, scratch)
         grads["f1b"] = bias_grad(cs, d.F1)
-        dx, _ = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
+        # Where the forward kept (out, gate) of every F.glu, the conv that produces the gradient entering a block's GLU (this
+        # 1x1 data gradient for block 4, conv0's data gradient of block k + 1 for block k) applies the GLU backward in its
+        # epilogue: `glu_pending` = (dc2, per-tile column sums) for the block about to be processed, and dx is never stored
+        glu_in_epilogue = bool(ctx.glu_fused and self.fuse_glu_backward and not self.flat_tiles_backward)
+        glu_pending = None
+        if glu_in_epilogue:
+            glu_pending = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dc2.4", 2 * d.D2p), 1, 0, glu_bwd=(bufs["x5"], bufs["b4.g"]))
+            dx = None
+        else:
+            dx, _ = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
         grads["f1w"] = wgrad(du1, bufs["x5"], 1, 0, d.F1, d.D2)
         flush(["f2w", "f2b", "f1w", "f1b"])
 
@@ -539,11 +559,15 @@ class EncoderEngine:
             cin, cin_p = (d.D1, d.D1p) if k == 0 else (d.D2, d.D2p)
             dil = block_dilations(k)
             glu = dict(glu_half=d.D2, glu_half_p=d.D2p)
-            dc2 = tmp(f"dc2.{k}", 2 * d.D2p)          # per-layer buffers: a side-stream wgrad may still read them
-            if ctx.glu_fused:
-                cs = ops.glu_backward_colsum_og(bufs[f"x{k + 1}"], bufs[f"b{k}.g"], dx, dc2, B, T, scratch)
+            if glu_pending is not None:
+                dc2, gst = glu_pending
+                cs = ops.reduce_stats(gst)                # [sum d value | sum d gate] over all rows
             else:
-                cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
+                dc2 = tmp(f"dc2.{k}", 2 * d.D2p)      # per-layer buffers: a side-stream wgrad may still read them
+                if ctx.glu_fused:
+                    cs = ops.glu_backward_colsum_og(bufs[f"x{k + 1}"], bufs[f"b{k}.g"], dx, dc2, B, T, scratch)
+                else:
+                    cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
             grads[f"b{k}.c2b"] = bias_grad(cs, 2 * d.D2, **glu)
             da1, tstats = dgrad(dc2, f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2],
                                 bn=(bufs[f"b{k}.h1"], ctx.bn[f"b{k}.bn1"][2]), **glu)
@@ -577,6 +601,10 @@ class EncoderEngine:
                     # the composed SubjectBlock takes its weight gradient straight from dh0 and X (below): the gradient with
                     # respect to x0 is never needed, this data-gradient conv is not run
                     da1, tstats, dh0 = None, None, dh
+                elif j == 0 and k > 0 and glu_in_epilogue:     # its output is the gradient entering block k - 1's GLU
+                    glu_pending = dgrad(dh, f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p, tmp(f"dc2.{k - 1}", 2 * d.D2p), 3, dil[j],
+                                        res=res, glu_bwd=(bufs[f"x{k}"], bufs[f"b{k - 1}.g"]))
+                    da1, tstats = None, None
                 else:
                     da1, tstats = dgrad(dh, f"b{k}.c{j}w", P[f"b{k}.c{j}w"], d.D2p, ci_p, out, 3, dil[j], res=res,
                                         bn=(bufs[f"b{k}.h0"], ctx.bn[f"b{k}.bn0"][2]) if j == 1 else None)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsdamd.so")
 F32, BF16, F16 = 0, 1, 2
 ROW_PAD = 16
 CH_ALIGN = 64
-EPI_GELU, EPI_GLU = 1, 2
+EPI_GELU, EPI_GLU, EPI_GLU_BWD = 1, 2, 4
 CONV_SINGLE_TILE, CONV_PAIR_TILES, CONV_FLAT_TILES, CONV_ONE_PER_CU = 4096, 8192, 16384, 32768
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
@@ -22,7 +22,7 @@ vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
 class ConvArgs(C.Structure):
     _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("res", vp), ("y", vp), ("y_pre", vp), ("widx", vp),
-                ("stats", vp), ("partial", vp), ("bn_x", vp), ("bn_coef", vp),
+                ("stats", vp), ("partial", vp), ("bn_x", vp), ("bn_coef", vp), ("glu_out", vp), ("glu_gate", vp),
                 ("B", i32), ("T", i32), ("Cin_p", i32), ("Cout_p", i32), ("KS", i32), ("dil", i32),
                 ("x_pitch", i64), ("w_pitch", i64), ("x_row0", i64), ("x_sample_rows", i64),
                 ("x_rows_limit", i64), ("w_rows_limit", i32), ("ksplit", i32), ("flags", i32), ("dtype", i32)]

@@ -282,7 +282,7 @@ def conv_tile_co(Cout_p: int, KS: int = 3, stats: bool = False) -> int:
 
 
 def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=None, stats=None, gelu=False,
-              alg_dims=None, flags=0, bn_x=None, bn_coef=None):
+              alg_dims=None, flags=0, bn_x=None, bn_coef=None, glu_bwd=None):
     """RL conv: x (rows, Cin_p), w (nW, KS, Cout_p, Cin_p) packed, y (rows, Cout_p).
     alg_dims = (Cin, Cout) unpadded, only used to count algorithmic FLOPs when the timer is on."""
     _need_cuda(x, w, y)
@@ -292,6 +292,12 @@ def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=N
     a.bn_x, a.bn_coef = _p(bn_x), _p(bn_coef)
     glu = bool(flags & L.EPI_GLU)        # y (and y_pre = the gate) are half as wide as the conv's output channels
     Cout_p = 2 * y.shape[1] if glu else y.shape[1]
+    if glu_bwd is not None:              # (out, gate) of the GLU this conv's output is the gradient of: y = [d value | d gate]
+        flags |= L.EPI_GLU_BWD
+        Cout_p = y.shape[1] // 2
+        if glu_bwd[0].shape[1] != Cout_p or glu_bwd[1].shape != glu_bwd[0].shape or stats is None:
+            raise L.SdaError("conv_gemm: glu_bwd needs (out, gate) of the conv's width and a stats buffer")
+        a.glu_out, a.glu_gate = _p(glu_bwd[0]), _p(glu_bwd[1])
     a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = B, T, x.shape[1], Cout_p, KS, dil
     if glu and (res is not None or stats is not None or bn_x is not None or (y_pre is not None and y_pre.shape != y.shape)):
         raise L.SdaError("conv_gemm: EPI_GLU takes no residual / statistics and a gate buffer of y's shape")
@@ -402,6 +408,14 @@ def bn_gelu_backward(dy, x, mean, rstd, gamma, beta, dx, B, T, scratch, count=No
                                            _p(dbeta), float(count if count is not None else B * T), _p(coef), _p(dx), B, T, Cp,
                                            dt_code(x.dtype), _st()), "bn_gelu_backward_apply")
     return dgamma, dbeta
+
+
+def reduce_stats(stats: torch.Tensor) -> torch.Tensor:
+    """Per-tile rows (n, 2, Cp) -> fp32 (2 * Cp,) = [column sums of slot 0 | of slot 1], summed in fixed order."""
+    Cp = stats.shape[2]
+    out = torch.empty(2 * Cp, dtype=torch.float32, device=stats.device)
+    L.check(L.load().sda_reduce_stats(_p(stats), stats.shape[0], _p(out), _p(out[Cp:]), Cp, _st()), "reduce_stats")
+    return out
 
 
 def glu_forward(x, y, B, T):

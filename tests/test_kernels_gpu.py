@@ -161,6 +161,39 @@ def test_conv3_glu_epilogue_equals_conv_then_glu(ops, dtype, cin, half, dil, T, 
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("KS,cin,H,dil,T,B", [(3, 320, 320, 4, 200, 3), (1, 640, 320, 0, 129, 2), (3, 96, 64, 2, 77, 3)])
+def test_conv_glu_backward_epilogue(ops, dtype, KS, cin, H, dil, T, B):
+    """EPI_GLU_BWD: a (data-gradient) conv whose output is the gradient entering an F.glu writes the GLU backward
+    [dy * sig(g) | dy * out * (1 - sig(g))] and the per-tile column sums of both halves, against conv -> glu_backward_colsum_og."""
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(KS + cin + H)
+    x = q(torch.randn(B, cin, T, generator=g), dtype)
+    w = q(torch.randn(H, cin, KS, generator=g) / math.sqrt(KS * cin), dtype)
+    res = q(torch.randn(B, H, T, generator=g), dtype)
+    out = q(torch.randn(B, H, T, generator=g), dtype)
+    gate = q(torch.randn(B, H, T, generator=g), dtype)
+    Cin_p, Hp = L.pad_channels(cin), L.pad_channels(H)
+    xb, resb, outb, gateb = (to_rows(ops, t, dtype) for t in (x, res, out, gate))
+    wp = ops.pack_conv_weight(w.to(DEV), Hp, Cin_p, dtype)
+    # reference path: the conv stores dy, a separate pass applies the GLU backward and sums the columns
+    dy = ops.conv_gemm(xb, wp, ops.new_rows(B, T, Hp, dtype, DEV), B=B, T=T, KS=KS, dil=dil, res=resb)
+    scratch = ops.reduce_scratch(2 * Hp, DEV)
+    want = ops.new_rows(B, T, 2 * Hp, dtype, DEV)
+    cs_want = ops.glu_backward_colsum_og(outb, gateb, dy, want, B, T, scratch)
+    got = ops.new_rows(B, T, 2 * Hp, dtype, DEV)
+    stats = torch.full((ops.conv_stats_rows(B, T, KS, Hp, 0), 2, Hp), float("nan"), device=DEV)
+    ops.conv_gemm(xb, wp, got, B=B, T=T, KS=KS, dil=dil, res=resb, stats=stats, glu_bwd=(outb, gateb))
+    t = tol(dtype, KS * cin)       # (the fused form multiplies the unrounded dy: one rounding less than the reference path)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want.float().cpu().numpy(), **t)
+    cs = ops.reduce_stats(stats)
+    ts = tol(dtype, B * T)
+    np.testing.assert_allclose(cs.cpu().numpy(), cs_want.cpu().numpy(), rtol=ts["rtol"], atol=ts["atol"] * 4)
+    assert float(got[: L.ROW_PAD].float().abs().max()) == 0.0                 # pad rows untouched
+    with pytest.raises(L.SdaError):                                           # not with the flat-tile kernel
+        ops.conv_gemm(xb, wp, got, B=B, T=T, KS=KS, dil=dil, stats=stats, glu_bwd=(outb, gateb), flags=L.CONV_FLAT_TILES)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv1_per_sample_weights_and_gelu(ops, dtype):
     from speech_decoding_amd import lib as L
     g = torch.Generator().manual_seed(3)
