@@ -116,6 +116,10 @@ class EncoderEngine:
         self._side = {}
         self._const = {}                     # persistent operand buffers (composed SubjectBlock matrices)
 
+        for key, val in os.environ.items():  # diagnostics: SDA_ENGINE_<attribute>=<python literal> overrides a switch above
+            if key.startswith("SDA_ENGINE_") and hasattr(self, key[11:]):
+                setattr(self, key[11:], eval(val))
+
     @property
     def world(self) -> int:
         if self.group is None:
@@ -286,11 +290,11 @@ class EncoderEngine:
             side = self._side.get(str(dev))
             if side is None:
                 side = self._side[str(dev)] = torch.cuda.Stream(device=dev, priority=self.side_stream_priority)
+            composed = self.composed
+            Xt = rows("Xt", d.Cp)                # (before the event: a first-use buffer is zero-filled on the MAIN stream)
             ev = torch.cuda.Event()
             ev.record(main)                      # the optimiser's update of P is on the main stream
             side.wait_event(ev)
-            composed = self.composed
-            Xt = rows("Xt", d.Cp)
             with torch.cuda.stream(side):
                 pk.update(fwd_plan.run(P))
                 # the input's layout change rides on the same stream: the main stream meanwhile computes the SpatialAttention
