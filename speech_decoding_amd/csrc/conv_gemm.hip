@@ -179,6 +179,26 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
 #pragma unroll
       for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af[m], bf[n], acc[m][n]);
   };
+  // The same with the next slab's LDS-DMA pieces spread over the tap: `piece(m)` runs after the m-th row of MFMAs (an issue
+  // costs ~100 cycles of the wave's issue slot; behind queued MFMAs the matrix pipe keeps working through it — one burst of
+  // all pieces in front of a tap's MFMAs, as above, stalls them), and each input fragment is read one MFMA row ahead.
+  auto compute_tap_spread = [&](const unsigned char* xs, const unsigned char* ws, int tap, auto&& piece) {
+    uint4 bf[NREP];
+    const int xrow = wave_t * 64 + lr + tap * dil;
+    const int wrow = tap * TILE_CO + wave_c * HALF_CO + lr;
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) bf[n] = *reinterpret_cast<const uint4*>(ws + lds_sw64(wrow + n * 16, lq));
+    uint4 af = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow, lq));
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      uint4 af_next = af;
+      if (m + 1 < 4) af_next = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow + (m + 1) * 16, lq));
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af, bf[n], acc[m][n]);
+      piece(m);
+      af = af_next;
+    }
+  };
 
   if constexpr (NS == 2) {
     if (s_begin < s_end) {
@@ -191,17 +211,39 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of slab s have landed
       __builtin_amdgcn_s_barrier();                       // ... everybody's have, and slab s-1 is fully consumed
       const bool more = s + 1 < s_end;
-      if (more) stage_x(s + 1, cur ^ 1);                  // DMA of the next slab overlaps the MFMAs below
       const unsigned char* xs = smem + cur * STAGE + tsel * XS_BYTES;
       const unsigned char* ws = smem + cur * STAGE + NT * XS_BYTES;
-#pragma unroll
-      for (int tap = 0; tap < KS; ++tap)
-        compute_tap(xs, ws, tap, [&] {
-          if (more && tap == 0) {
-#pragma unroll
-            for (int t2 = 0; t2 < KS; ++t2) stage_w(s + 1, cur ^ 1, t2);
+      if constexpr (NT == 1 && SV) {
+        // this wave's pieces of slab s + 1 in need order (input first), PER of them after each row of MFMAs
+        constexpr int NXW = 3, NWW = (KS * TP + NW - 1) / NW, PER = (NXW + NWW + 4 * KS - 1) / (4 * KS);
+        auto issue_j = [&](int j) {
+          if (j < NXW) {
+            const int pc = (wid & 3) + 4 * j;
+            if (pc < x_pieces) dma_x(s + 1, pc, (cur ^ 1) * STAGE + tsel * XS_BYTES + pc * 1024);
+          } else if (j < NXW + NWW) {
+            const int q = wid + NW * (j - NXW);
+            if (q < KS * TP) { const int t2 = q / TP; dma_w(s + 1, t2, q - t2 * TP, (cur ^ 1) * STAGE + NT * XS_BYTES + q * 1024); }
           }
-        });
+        };
+#pragma unroll
+        for (int tap = 0; tap < KS; ++tap)
+          compute_tap_spread(xs, ws, tap, [&](int m) {
+            if (more) {
+#pragma unroll
+              for (int i = 0; i < PER; ++i) issue_j((tap * 4 + m) * PER + i);
+            }
+          });
+      } else {
+        if (more) stage_x(s + 1, cur ^ 1);                // DMA of the next slab overlaps the MFMAs below
+#pragma unroll
+        for (int tap = 0; tap < KS; ++tap)
+          compute_tap(xs, ws, tap, [&] {
+            if (more && tap == 0) {
+#pragma unroll
+              for (int t2 = 0; t2 < KS; ++t2) stage_w(s + 1, cur ^ 1, t2);
+            }
+          });
+      }
     }
   } else {
     // Three LDS stages, two slabs in flight: every wave issues EXACTLY 3 input pieces + 4 weight pieces per
