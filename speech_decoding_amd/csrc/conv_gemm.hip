@@ -182,21 +182,32 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
   // The same with the next slab's LDS-DMA pieces spread over the tap: `piece(m)` runs after the m-th row of MFMAs (an issue
   // costs ~100 cycles of the wave's issue slot; behind queued MFMAs the matrix pipe keeps working through it — one burst of
   // all pieces in front of a tap's MFMAs, as above, stalls them), and each input fragment is read one MFMA row ahead.
-  auto compute_tap_spread = [&](const unsigned char* xs, const unsigned char* ws, int tap, auto&& piece) {
-    uint4 bf[NREP];
-    const int xrow = wave_t * 64 + lr + tap * dil;
-    const int wrow = tap * TILE_CO + wave_c * HALF_CO + lr;
+  // `piece(tap, m)` runs after MFMA row m of tap `tap`; the NEXT tap's weight fragments and first input fragment are read
+  // during the current tap's rows (all taps of a slab sit in the same LDS stage), so only a slab's first tap waits for LDS.
+  auto compute_slab_spread = [&](const unsigned char* xs, const unsigned char* ws, auto&& piece) {
+    uint4 bf[2][NREP];
+    const int wrow0 = wave_c * HALF_CO + lr, xrow0 = wave_t * 64 + lr;
 #pragma unroll
-    for (int n = 0; n < NREP; ++n) bf[n] = *reinterpret_cast<const uint4*>(ws + lds_sw64(wrow + n * 16, lq));
-    uint4 af = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow, lq));
+    for (int n = 0; n < NREP; ++n) bf[0][n] = *reinterpret_cast<const uint4*>(ws + lds_sw64(wrow0 + n * 16, lq));
+    uint4 af = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow0, lq));
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      uint4 af_next = af;
-      if (m + 1 < 4) af_next = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow + (m + 1) * 16, lq));
+    for (int tap = 0; tap < KS; ++tap) {
+      const int xrow = xrow0 + tap * dil;
 #pragma unroll
-      for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af, bf[n], acc[m][n]);
-      piece(m);
-      af = af_next;
+      for (int m = 0; m < 4; ++m) {
+        uint4 af_next = af;
+        if (m + 1 < 4) af_next = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow + (m + 1) * 16, lq));
+        else if (tap + 1 < KS) af_next = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow0 + (tap + 1) * dil, lq));
+        if (m == 1 && tap + 1 < KS) {
+#pragma unroll
+          for (int n = 0; n < NREP; ++n)
+            bf[(tap + 1) & 1][n] = *reinterpret_cast<const uint4*>(ws + lds_sw64((tap + 1) * TILE_CO + wrow0 + n * 16, lq));
+        }
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af, bf[tap & 1][n], acc[m][n]);
+        piece(tap, m);
+        af = af_next;
+      }
     }
   };
 
@@ -225,14 +236,12 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
             if (q < KS * TP) { const int t2 = q / TP; dma_w(s + 1, t2, q - t2 * TP, (cur ^ 1) * STAGE + NT * XS_BYTES + q * 1024); }
           }
         };
+        compute_slab_spread(xs, ws, [&](int tap, int m) {
+          if (more) {
 #pragma unroll
-        for (int tap = 0; tap < KS; ++tap)
-          compute_tap_spread(xs, ws, tap, [&](int m) {
-            if (more) {
-#pragma unroll
-              for (int i = 0; i < PER; ++i) issue_j((tap * 4 + m) * PER + i);
-            }
-          });
+            for (int i = 0; i < PER; ++i) issue_j((tap * 4 + m) * PER + i);
+          }
+        });
       } else {
         if (more) stage_x(s + 1, cur ^ 1);                // DMA of the next slab overlaps the MFMAs below
 #pragma unroll
