@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-steps", type=int, default=3, help="instrumented steps run after the timed region")
+    ap.add_argument("--no-prefetch-ahead", action="store_true", help="N > 1: gather each step's speech rows at its own start")
     ap.add_argument("--no-host-sync-leg", action="store_true", help="skip the extra loop that reads loss/ranks back every step")
     return ap.parse_args()
 
@@ -232,13 +233,23 @@ def main():
 
     ranks_acc = []
 
+    # Under data parallelism the speech rows of the NEXT batch are packed and all-gathered (197 MB per rank and step at
+    # config 3) while THIS step's backward runs, like a data loader that is one batch ahead: five milliseconds of cover
+    # instead of the forward's two and a half.  The loss keeps two packed buffers in rotation for exactly this overlap.
+    ahead = world > 1 and not a.no_prefetch_ahead
+    primed = [False]
+
     def step(i, host_sync=False):
         X, Y = pool[i % len(pool)]
         subj = torch.from_numpy(subj_rng.randint(0, S, size=B).astype(np.int32))
-        lossf.prefetch(Y, enc.compute_dtype)                 # pack Y (+ all-gather it under DP) while the encoder runs
+        if not (ahead and primed[0]):
+            lossf.prefetch(Y, enc.compute_dtype)             # pack Y (+ all-gather it under DP) while the encoder runs
         Z = enc(X, subj)
         loss = lossf(Y, Z)
         cnt = sda_loss.retrieval_ranks(Y, Z)                 # Classifier semantics (train.py:193-194)
+        if ahead:
+            lossf.prefetch(pool[(i + 1) % len(pool)][1], enc.compute_dtype)
+            primed[0] = True
         if host_sync:                                        # what train.py does every step: loss.item() + top-k on the host
             float(loss.detach())
             cnt = cnt.cpu()
