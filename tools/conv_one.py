@@ -16,7 +16,7 @@ def main():
     wp = ops.pack_conv_weight(w, cout, cin, dtype)
     y = ops.new_rows(B, T, cout, dtype, dev)
     bias = torch.zeros(cout, device=dev)
-    stats = torch.zeros((B * ops.n_t_tiles(T), 2, cout), device=dev)
+    stats = torch.zeros((ops.conv_stats_rows(B, T, KS, cout, flags), 2, cout), device=dev)
     res = x if cin == cout else None
     if what == "conv":
         for _ in range(n):

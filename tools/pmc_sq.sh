@@ -13,7 +13,7 @@ for p in ("p1", "p2", "p3"):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "conv_gemm" not in k and "wgrad_gemm" not in k: continue
+            if "conv_gemm" not in k and "wgrad_gemm" not in k and "conv3_flat" not in k: continue
             a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
         for c, (v, n) in sorted(acc.items()):
             print("$tag %-32s %14.0f per launch (n=%d)" % (c, v / n, n))
