@@ -196,6 +196,9 @@ int sda_glu_backward(const void* x, const void* dy, void* dx, int B, int T, int 
 int sda_gelu_backward(const void* u, const void* dz, void* du, int B, int T, int Cp, int dtype, void* stream);
 /* the same two backward stages fused with the column sums of their own output (= the bias gradient of the
  * layer that produced x / u): colsum fp32 [2*Ch] resp. [Cp]; scratch sda_reduce_scratch_floats(.) floats */
+/* (colsum == NULL: the final reduction is left to the caller — scratch then holds sda_reduce_scratch_rows(B, T) rows of
+ * [2][Ch] (resp. [2][Cp], slot 1 unused) partial sums for sda_reduce_stats, e.g. on another stream) */
+int sda_reduce_scratch_rows(int B, int T);
 int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, float* colsum, float* scratch, int B, int T,
                             int Ch, int dtype, void* stream);
 int sda_gelu_backward_colsum(const void* u, const void* dz, void* du, float* colsum, float* scratch, int B, int T,

@@ -1007,6 +1007,7 @@ extern "C" int sda_colsum(const void* x, float* out, float* scratch, int B, int 
 }
 
 extern "C" int sda_reduce_scratch_floats(int Cp) { return RED_MAX_BLOCKS * 2 * Cp; }
+extern "C" int sda_reduce_scratch_rows(int B, int T) { return red_blocks(B, T); }
 
 extern "C" int sda_glu_forward(const void* x, void* y, int B, int T, int Ch, int dtype, void* stream) {
   if (!x || !y || Ch % 64 || !fits_u32(B, T, 2L * Ch)) { set_error("glu_forward: bad arguments"); return -1; }
@@ -1031,37 +1032,37 @@ extern "C" int sda_gelu_backward(const void* u, const void* dz, void* du, int B,
 
 extern "C" int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, float* colsum, float* scratch, int B, int T,
                                        int Ch, int dtype, void* stream) {
-  if (!x || !dy || !dx || !colsum || !scratch || Ch % 64 || Ch > 1024 || !fits_u32(B, T, 2L * Ch)) { set_error("glu_backward_colsum: bad arguments"); return -1; }
+  if (!x || !dy || !dx || !scratch || Ch % 64 || Ch > 1024 || !fits_u32(B, T, 2L * Ch)) { set_error("glu_backward_colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
   const size_t lds = (size_t)(256 / (Ch / (dtype == SDA_F32 ? 4 : 8))) * 2 * Ch * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)x,
                                          (const E*)dy, (E*)dx, scratch, B, T, Ch));
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
+  if (colsum) hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
   return check_launch("glu_backward_colsum");
 }
 
 extern "C" int sda_glu_backward_colsum_og(const void* out, const void* gate, const void* dy, void* dx, float* colsum,
                                           float* scratch, int B, int T, int Ch, int dtype, void* stream) {
-  if (!out || !gate || !dy || !dx || !colsum || !scratch || Ch % 64 || Ch > 1024 || !fits_u32(B, T, 2L * Ch)) { set_error("glu_backward_colsum_og: bad arguments"); return -1; }
+  if (!out || !gate || !dy || !dx || !scratch || Ch % 64 || Ch > 1024 || !fits_u32(B, T, 2L * Ch)) { set_error("glu_backward_colsum_og: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
   const size_t lds = (size_t)(256 / (Ch / (dtype == SDA_F32 ? 4 : 8))) * 2 * Ch * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 2>), dim3(nb), dim3(256), lds, st, (const E*)out,
                                          (const E*)dy, (E*)dx, scratch, B, T, Ch, (const E*)gate));
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
+  if (colsum) hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
   return check_launch("glu_backward_colsum_og");
 }
 
 extern "C" int sda_gelu_backward_colsum(const void* u, const void* dz, void* du, float* colsum, float* scratch, int B, int T,
                                         int Cp, int dtype, void* stream) {
-  if (!u || !dz || !du || !colsum || !scratch || Cp % 64 || Cp > 1024 || !fits_u32(B, T, Cp)) { set_error("gelu_backward_colsum: bad arguments"); return -1; }
+  if (!u || !dz || !du || !scratch || Cp % 64 || Cp > 1024 || !fits_u32(B, T, Cp)) { set_error("gelu_backward_colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
   const size_t lds = (size_t)(256 / (Cp / (dtype == SDA_F32 ? 4 : 8))) * 2 * Cp * sizeof(float);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)u,
                                          (const E*)dz, (E*)du, scratch, B, T, Cp));
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, (float*)nullptr, Cp);
+  if (colsum) hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, (float*)nullptr, Cp);
   return check_launch("gelu_backward_colsum");
 }
 

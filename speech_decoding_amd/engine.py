@@ -98,6 +98,7 @@ class EncoderEngine:
         self.flat_tile_options = 0           # extra conv3_flat flags: 1024 = co-resident workgroups take their tiles in opposite
                                              # order, 64 = static priority for one workgroup of each pair
         self.fuse_glu_forward = True         # F.glu in conv2's epilogue (flat-tile kernel, D2p % 80 == 0): no [value | gate] buffer
+        self.bias_sums_on_side = True        # final reduction of the bias-gradient column sums on the weight-gradient stream
         self.fuse_glu_backward = False       # the GLU backward in the epilogue of the conv that produces its incoming gradient
                                              # (needs the fused forward: bufs hold (out, gate)); not with flat-tile data gradients.
                                              # Off: measured 7.87 vs 7.77 ms — the separate pass is HBM-bound and runs beside the
@@ -535,13 +536,20 @@ class EncoderEngine:
             return ops.unpack_vector(cs, C, glu_half, glu_half_p)
 
         # ---- final projections
+        # the last stage of a bias gradient (partial rows -> column sums) feeds nothing on the main stream: it goes to the
+        # weight-gradient stream, each launch with partial rows of its own
+        def colsum_on_side(fn, *args, width):
+            if side is None or not self.bias_sums_on_side:
+                return fn(*args, B, T, scratch)
+            return on_side(fn(*args, B, T, ops.reduce_scratch(width, dev), defer=True))
+
         du2 = tmp("du2", d.Fp)
-        cs = ops.gelu_backward_colsum(bufs["u2"], dZt, du2, B, T, scratch)
+        cs = colsum_on_side(ops.gelu_backward_colsum, bufs["u2"], dZt, du2, width=d.Fp)
         grads["f2b"] = bias_grad(cs, d.F)
         dg1, _ = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
         grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
         du1 = tmp("du1", d.F1p)
-        cs = ops.gelu_backward_colsum(bufs["u1"], dg1, du1, B, T, scratch)
+        cs = colsum_on_side(ops.gelu_backward_colsum, bufs["u1"], dg1, du1, width=d.F1p)
         grads["f1b"] = bias_grad(cs, d.F1)
         # Where the forward kept (out, gate) of every F.glu, the conv that produces the gradient entering a block's GLU (this
         # 1x1 data gradient for block 4, conv0's data gradient of block k + 1 for block k) applies the GLU backward in its
@@ -569,7 +577,7 @@ class EncoderEngine:
             else:
                 dc2 = tmp(f"dc2.{k}", 2 * d.D2p)      # per-layer buffers: a side-stream wgrad may still read them
                 if ctx.glu_fused:
-                    cs = ops.glu_backward_colsum_og(bufs[f"x{k + 1}"], bufs[f"b{k}.g"], dx, dc2, B, T, scratch)
+                    cs = colsum_on_side(ops.glu_backward_colsum_og, bufs[f"x{k + 1}"], bufs[f"b{k}.g"], dx, dc2, width=2 * d.D2p)
                 else:
                     cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
             grads[f"b{k}.c2b"] = bias_grad(cs, 2 * d.D2, **glu)

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sda_glu_forward": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sda_glu_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_gelu_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_reduce_scratch_rows": (i32, [i32, i32]),
     "sda_glu_backward_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_w2v_conv0": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
     "sda_layernorm_rows": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp]),

@@ -441,20 +441,36 @@ def glu_backward_colsum(x, dy, dx, B, T, scratch):
     return cs
 
 
-def glu_backward_colsum_og(out, gate, dy, dx, B, T, scratch):
+def _deferred_colsum(scratch, B, T, width, two):
+    """finish() for a column-sum kernel launched without its final reduction: sums the partial rows left in `scratch`
+    on whatever stream is current when it is called (the caller orders that stream after the producing launch)."""
+    nb = L.load().sda_reduce_scratch_rows(B, T)
+
+    def finish():
+        scratch.record_stream(torch.cuda.current_stream(scratch.device))     # allocated on the producer's stream, read on this one
+        cs = torch.empty((2 if two else 1) * width, dtype=torch.float32, device=scratch.device)
+        L.check(L.load().sda_reduce_stats(_p(scratch), nb, _p(cs), _p(cs[width:]) if two else None, width, _st()), "reduce_stats")
+        return cs
+    return finish
+
+
+def glu_backward_colsum_og(out, gate, dy, dx, B, T, scratch, defer=False):
     """GLU backward after a fused forward (conv_gemm(flags=EPI_GLU)): `out` = value * sigmoid(gate) and `gate` instead of the
-    [value | gate] buffer; same dx ([d value | d gate]) and column sums as glu_backward_colsum."""
-    cs = torch.empty(2 * dy.shape[1], dtype=torch.float32, device=dy.device)
-    L.check(L.load().sda_glu_backward_colsum_og(_p(out), _p(gate), _p(dy), _p(dx), _p(cs), _p(scratch), B, T, dy.shape[1],
+    [value | gate] buffer; same dx ([d value | d gate]) and column sums as glu_backward_colsum.  defer=True: returns finish()
+    instead of the sums (the final reduction of the per-workgroup partial rows is then the caller's to place; `scratch` must
+    be a buffer of this call's own)."""
+    Ch = dy.shape[1]
+    cs = None if defer else torch.empty(2 * Ch, dtype=torch.float32, device=dy.device)
+    L.check(L.load().sda_glu_backward_colsum_og(_p(out), _p(gate), _p(dy), _p(dx), _p(cs), _p(scratch), B, T, Ch,
                                                 dt_code(dy.dtype), _st()), "glu_backward_colsum_og")
-    return cs
+    return _deferred_colsum(scratch, B, T, Ch, True) if defer else cs
 
 
-def gelu_backward_colsum(u, dz, du, B, T, scratch):
-    cs = torch.empty(u.shape[1], dtype=torch.float32, device=u.device)
+def gelu_backward_colsum(u, dz, du, B, T, scratch, defer=False):
+    cs = None if defer else torch.empty(u.shape[1], dtype=torch.float32, device=u.device)
     L.check(L.load().sda_gelu_backward_colsum(_p(u), _p(dz), _p(du), _p(cs), _p(scratch), B, T, u.shape[1], dt_code(u.dtype), _st()),
             "gelu_backward_colsum")
-    return cs
+    return _deferred_colsum(scratch, B, T, u.shape[1], False) if defer else cs
 
 
 def colsum(x, B, T, scratch):
