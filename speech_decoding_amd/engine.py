@@ -10,6 +10,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
+import ast
 import os
 
 import numpy as np
@@ -119,7 +120,7 @@ class EncoderEngine:
 
         for key, val in os.environ.items():  # diagnostics: SDA_ENGINE_<attribute>=<python literal> overrides a switch above
             if key.startswith("SDA_ENGINE_") and hasattr(self, key[11:]):
-                setattr(self, key[11:], eval(val))
+                setattr(self, key[11:], ast.literal_eval(val))
 
     @property
     def world(self) -> int:
