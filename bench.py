@@ -295,12 +295,18 @@ def main():
     cnt = torch.cat([c.to(dev) for c in ranks_acc[-3:]]).float()
     top10 = float((cnt < 10).float().mean())
     final_loss = float(loss.detach())
+    # (fp16 runs with a STATIC loss scale here — no per-step host check inside the timed region; train.py checks every step.
+    # An overflow would have poisoned the weights: verify after the fact that it did not)
+    if not all(bool(torch.isfinite(torch.view_as_real(p) if p.is_complex() else p).all()) for p in params):
+        raise SystemExit("bench.py: non-finite parameters after the timed region (fp16 overflow?) - the number is void")
 
-    dt_sync = None
+    nxt = a.warmup + a.steps                                 # step indices stay contiguous across the legs: under N > 1 the
+    dt_sync = None                                           # speech rows of step i + 1 were prefetched by step i
     if not a.no_host_sync_leg:                               # same step with the reference loop's per-step host readbacks
         n_sync = max(3, min(10, a.steps))
-        dt_sync, _ = timed(n_sync, a.warmup + a.steps, host_sync=True)
+        dt_sync, _ = timed(n_sync, nxt, host_sync=True)
         dt_sync /= n_sync
+        nxt += n_sync
 
     timer = None
     if not a.no_kernel_timer and a.timer_steps > 0:          # roofline leg, outside the timed region
@@ -308,7 +314,7 @@ def main():
         fence()
         ops.TIMER = timer
         for i in range(a.timer_steps):
-            step(a.warmup + a.steps + 20 + i)
+            step(nxt + i)
         fence()
         ops.TIMER = None
 

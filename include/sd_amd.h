@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 1
+#define SDA_ABI_VERSION 2   /* 2: sda_conv_args gained glu_out / glu_gate, sda_pack_desc gained glu_tile, flag 16384 = SDA_CONV_FLAT_TILES */
 #define SDA_ROW_PAD 16
 #define SDA_CH_ALIGN 64
 

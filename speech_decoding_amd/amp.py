@@ -8,7 +8,9 @@ none of this (`LossScaler(1)` is a no-op).
 
     scaler = LossScaler.for_dtype(brain_encoder.compute_dtype)
     scaler.scale(loss).backward()
-    scaler.unscale_(params)           # before the all-reduce / optimiser step
+    ok = scaler.unscale_(params, check=True)      # before the all-reduce / optimiser step; check=True is a host sync
+    scaler.update(ok)                             # overflow: halve the scale ...
+    if ok: optimizer.step()                       # ... and skip the step
 """
 from __future__ import annotations
 
@@ -20,8 +22,11 @@ DEFAULT_FP16_SCALE = 1024.0
 
 
 class LossScaler:
-    def __init__(self, scale: float = 1.0):
+    def __init__(self, scale: float = 1.0, growth_interval: int = 2000):
         self.scale_value = float(scale)
+        self.growth_interval = int(growth_interval)
+        self._good_steps = 0
+        self.skipped_steps = 0
 
     @classmethod
     def for_dtype(cls, dtype: torch.dtype, scale: float = DEFAULT_FP16_SCALE) -> "LossScaler":
@@ -42,3 +47,19 @@ class LossScaler:
         if not check:
             return True
         return bool(torch.isfinite(torch.stack([g.abs().max() for g in grads])).all())
+
+    def update(self, ok: bool) -> None:
+        """Dynamic scaling, for callers that pass check=True to unscale_() (torch.cuda.amp.GradScaler's rule): a step whose
+        gradients were not finite is skipped by the caller and halves the scale; `growth_interval` good steps in a row
+        double it.  A scale of 1 (bf16 / fp32) never changes."""
+        if self.scale_value == 1.0:
+            return
+        if not ok:
+            self.scale_value = max(1.0, self.scale_value * 0.5)
+            self._good_steps = 0
+            self.skipped_steps += 1
+            return
+        self._good_steps += 1
+        if self._good_steps >= self.growth_interval:
+            self.scale_value = min(65536.0, self.scale_value * 2.0)
+            self._good_steps = 0

@@ -118,9 +118,22 @@ class EncoderEngine:
         self._side = {}
         self._const = {}                     # persistent operand buffers (composed SubjectBlock matrices)
 
-        for key, val in os.environ.items():  # diagnostics: SDA_ENGINE_<attribute>=<python literal> overrides a switch above
-            if key.startswith("SDA_ENGINE_") and hasattr(self, key[11:]):
-                setattr(self, key[11:], ast.literal_eval(val))
+        # diagnostics: SDA_ENGINE_<switch>=<python literal> overrides one of the SWITCHES above (plain bool / int / float
+        # attributes set in this constructor: never a property, a buffer table or the dims)
+        switches = {k for k, v in vars(self).items() if not k.startswith("_") and isinstance(v, (bool, int, float))}
+        for key, val in os.environ.items():
+            if not key.startswith("SDA_ENGINE_"):
+                continue
+            name = key[11:]
+            if name not in switches:
+                raise L.SdaError(f"{key}: no such engine switch (known: {', '.join(sorted(switches))})")
+            try:
+                lit = ast.literal_eval(val)
+            except (ValueError, SyntaxError) as e:
+                raise L.SdaError(f"{key}={val!r} is not a Python literal: {e}") from None
+            if not isinstance(lit, (bool, int, float)):
+                raise L.SdaError(f"{key}={val!r}: a switch takes a bool, int or float")
+            setattr(self, name, lit)
 
     @property
     def world(self) -> int:
@@ -539,19 +552,21 @@ class EncoderEngine:
         # ---- final projections
         # the last stage of a bias gradient (partial rows -> column sums) feeds nothing on the main stream: it goes to the
         # weight-gradient stream, each launch with partial rows of its own
-        def colsum_on_side(fn, *args, width):
+        def colsum_on_side(fn, *args, width, then=None):
+            """Column sums of fn's output; `then` (the bias-gradient un-packing, where it needs a kernel) runs on the SAME
+            stream as the sums' final reduction, right behind it: on the main stream it would read them before they exist."""
             if side is None or not self.bias_sums_on_side:
-                return fn(*args, B, T, scratch)
-            return on_side(fn(*args, B, T, ops.reduce_scratch(width, dev), defer=True))
+                cs = fn(*args, B, T, scratch)
+                return then(cs) if then is not None else cs
+            finish = fn(*args, B, T, ops.reduce_scratch(width, dev), defer=True)
+            return on_side((lambda: then(finish())) if then is not None else finish)
 
         du2 = tmp("du2", d.Fp)
-        cs = colsum_on_side(ops.gelu_backward_colsum, bufs["u2"], dZt, du2, width=d.Fp)
-        grads["f2b"] = bias_grad(cs, d.F)
+        grads["f2b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u2"], dZt, du2, width=d.Fp, then=lambda cs: bias_grad(cs, d.F))
         dg1, _ = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
         grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
         du1 = tmp("du1", d.F1p)
-        cs = colsum_on_side(ops.gelu_backward_colsum, bufs["u1"], dg1, du1, width=d.F1p)
-        grads["f1b"] = bias_grad(cs, d.F1)
+        grads["f1b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u1"], dg1, du1, width=d.F1p, then=lambda cs: bias_grad(cs, d.F1))
         # Where the forward kept (out, gate) of every F.glu, the conv that produces the gradient entering a block's GLU (this
         # 1x1 data gradient for block 4, conv0's data gradient of block k + 1 for block k) applies the GLU backward in its
         # epilogue: `glu_pending` = (dc2, per-tile column sums) for the block about to be processed, and dx is never stored
@@ -572,16 +587,17 @@ class EncoderEngine:
             cin, cin_p = (d.D1, d.D1p) if k == 0 else (d.D2, d.D2p)
             dil = block_dilations(k)
             glu = dict(glu_half=d.D2, glu_half_p=d.D2p)
+            c2b = lambda cs: bias_grad(cs, 2 * d.D2, **glu)          # noqa: E731  (a kernel when D2 is not a multiple of 64)
             if glu_pending is not None:
                 dc2, gst = glu_pending
-                cs = ops.reduce_stats(gst)                # [sum d value | sum d gate] over all rows
+                grads[f"b{k}.c2b"] = c2b(ops.reduce_stats(gst))   # [sum d value | sum d gate] over all rows
             else:
                 dc2 = tmp(f"dc2.{k}", 2 * d.D2p)      # per-layer buffers: a side-stream wgrad may still read them
                 if ctx.glu_fused:
-                    cs = colsum_on_side(ops.glu_backward_colsum_og, bufs[f"x{k + 1}"], bufs[f"b{k}.g"], dx, dc2, width=2 * d.D2p)
+                    grads[f"b{k}.c2b"] = colsum_on_side(ops.glu_backward_colsum_og, bufs[f"x{k + 1}"], bufs[f"b{k}.g"], dx, dc2,
+                                                        width=2 * d.D2p, then=c2b)
                 else:
-                    cs = ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch)
-            grads[f"b{k}.c2b"] = bias_grad(cs, 2 * d.D2, **glu)
+                    grads[f"b{k}.c2b"] = c2b(ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch))
             da1, tstats = dgrad(dc2, f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2],
                                 bn=(bufs[f"b{k}.h1"], ctx.bn[f"b{k}.bn1"][2]), **glu)
             # the weight-gradient chain is queued AFTER the data-gradient conv: on the side stream it then runs

@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdamd.so")
 
+ABI_VERSION = 2          # SDA_ABI_VERSION of include/sd_amd.h this binding was written against
 F32, BF16, F16 = 0, 1, 2
 ROW_PAD = 16
 CH_ALIGN = 64
@@ -126,7 +127,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.sda_abi_version() != 1:
+    if lib.sda_abi_version() != ABI_VERSION:
         raise SdaError("libsdamd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -19,7 +19,7 @@ from . import engine as E
 
 import weakref
 
-_rank_cache = []          # [(weakref(Y), weakref(Z), ranks)] from the last CLIPLoss forward (keyed by tensor IDENTITY)
+_rank_cache = []          # [(weakref(Y), weakref(Z), Y._version, Z._version, ranks)] from the last CLIPLoss forward
 
 
 class LossState:
@@ -54,12 +54,15 @@ class RingSlot:
 
 def _cache_ranks(Y, Z, cnt):
     _rank_cache.clear()
-    _rank_cache.append((weakref.ref(Y), weakref.ref(Z), cnt))
+    _rank_cache.append((weakref.ref(Y), weakref.ref(Z), Y._version, Z._version, cnt))
 
 
 def _cached_ranks(Y, Z):
-    for wy, wz, cnt in _rank_cache:
-        if wy() is Y and wz() is Z:
+    """Ranks of the last CLIPLoss forward — valid for the SAME two tensor objects while neither has been written in place
+    since (torch's version counters, as ops.ROW_NORMS checks them): an edit of Z between loss_func(Y, Z) and
+    classifier(Z, Y) sends the classifier back to computing its own ranks."""
+    for wy, wz, vy, vz, cnt in _rank_cache:
+        if wy() is Y and wz() is Z and Y._version == vy and Z._version == vz:
             return cnt
     return None
 

@@ -37,7 +37,9 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert n in lib.SIGNATURES, f"{n} has no ctypes signature in lib.py"
     assert set(lib.SIGNATURES) == set(names)
     L = lib.load()
-    assert L.sda_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "sd_amd.h")).read()
+    declared = int(re.search(r"#define\s+SDA_ABI_VERSION\s+(\d+)", header).group(1))
+    assert L.sda_abi_version() == declared == lib.ABI_VERSION == 2
 
 
 def test_layout_helpers_agree_with_python_mirror(lib):

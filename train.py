@@ -109,13 +109,20 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
     from speech_decoding_amd.amp import LossScaler
     scaler = LossScaler.for_dtype(brain_encoder.compute_dtype, float(args.get("fp16_loss_scale", 1024.0)))   # no-op unless fp16
 
+    fp16 = scaler.scale_value != 1.0
+
     def backward_and_step(loss):
         optimizer.zero_grad()
         scaler.scale(loss).backward()
-        scaler.unscale_(params)
-        if world > 1:
+        if world > 1:        # (SUM of the still-scaled gradients: every rank then sees the same overflow, or none)
             allreduce_gradients(list(loss_func.parameters()) if brain_encoder.grads_are_reduced else params)
-        optimizer.step()
+        # fp16 only: an activation gradient that overflowed to inf / NaN must not reach Adam — the finiteness check is a
+        # host read-back per step (fp16 is configs[4]'s dtype; bf16 / fp32 never take it), the step is skipped and the
+        # scale halved (amp.LossScaler.update, GradScaler's rule)
+        ok = scaler.unscale_(params, check=fp16)
+        scaler.update(ok)
+        if ok:
+            optimizer.step()
 
     history = []
     for epoch in range(int(args.epochs)):
