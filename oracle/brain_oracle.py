@@ -84,12 +84,18 @@ def spatial_attention(P, X: Tensor, mask: Optional[Tensor]) -> Tensor:
     return torch.einsum("oc,bct->bot", W.to(X.dtype), X)
 
 
-def subject_block(P, X: Tensor, subject_idxs, mask: Optional[Tensor]) -> Tensor:
+def subject_block(P, X: Tensor, subject_idxs, mask: Optional[Tensor], taps: Optional[dict] = None) -> Tensor:
     """models.py:111-117 — SA → shared 1×1 (bias) → per-subject 1×1 (no bias).
 
-    The per-sample Python loop (114-116) is restated as a gathered batched matmul."""
+    The per-sample Python loop (114-116) is restated as a gathered batched matmul.
+    `taps` (tests only): receives the shared conv's output with its gradient retained — the terms whose sum over
+    (batch, time) is that conv's bias gradient."""
     H = spatial_attention(P, X, mask)
     H = TF.conv1d(H, P["subject_block.conv.weight"], P["subject_block.conv.bias"])
+    if taps is not None:
+        if H.requires_grad:
+            H.retain_grad()
+        taps["subject_block.conv.out"] = H
     idx = torch.as_tensor(subject_idxs).long().tolist()
     Ws = torch.stack([P[f"subject_block.subject_layer.{s}.weight"][:, :, 0] for s in idx])
     return torch.bmm(Ws, H)
@@ -146,12 +152,12 @@ def conv_block(P, x: Tensor, k: int, training: bool, stats: Optional[dict]) -> T
 
 def brain_encoder_forward(P, X: Tensor, subject_idxs, *, training: bool, loc: Optional[Tensor] = None,
                           drop_centre: Optional[int] = None, d_drop: float = 0.1,
-                          stats: Optional[dict] = None) -> Tensor:
+                          stats: Optional[dict] = None, taps: Optional[dict] = None) -> Tensor:
     """models.py:191-196.  `drop_centre` replaces the NumPy global-RNG draw at models.py:81 so tests
     can inject it; in eval mode (training=False) dropout is the identity and BN uses running stats.
     `stats` (dict of running_mean/var/num_batches_tracked clones) receives the BN updates."""
     mask = dropout_mask(loc, drop_centre, d_drop) if (training and drop_centre is not None) else None
-    h = subject_block(P, X, subject_idxs, mask)
+    h = subject_block(P, X, subject_idxs, mask, taps)
     for k in range(5):
         h = conv_block(P, h, k, training, stats)
     h = TF.gelu(TF.conv1d(h, P["conv_final1.weight"], P["conv_final1.bias"]))
@@ -180,6 +186,50 @@ def clip_loss(Y: Tensor, Z: Tensor, temp: Tensor, reduction: str = "mean") -> Tu
     loss = (TF.cross_entropy(logits, tgt, reduction=reduction)
             + TF.cross_entropy(logits.t(), tgt, reduction=reduction)) / 2
     return loss, logits
+
+
+def clip_loss_blockwise(Y: Tensor, Zsrc: Tensor, col_src, temp: Tensor, *, grad_blocks=(), chunk: int = 32768,
+                        reduction: str = "mean") -> dict:
+    """loss.py:58-79 (fast path) and its gradient for batches too large for autograd's saved copies — the loss block of the
+    data-parallel configurations at full size (2048 / 4096 speech rows, contraction length up to 1 024 000).
+
+    Y: (B, N) speech rows.  The B brain rows are given indirectly: brain row j is Zsrc[col_src[j]] (Zsrc: (M, N) with
+    M <= B distinct rows; col_src: length-B index list), so a test can repeat a block of columns without the CPU paying for
+    the repeated similarity products.  Same function of (Y, Z, temp) as clip_loss: only the order of the arithmetic differs —
+    the two big contractions (Y Z^T and dS^T Y) run in column chunks of fp32 matmuls accumulated in fp64, and the chain
+    rule through the small (B x B) tail is autograd's.  Returns loss, logits (B, B), dtemp and, for every j0:j1 in
+    `grad_blocks`, dZ[(j0, j1)] = d loss / d Z[j0:j1] (B_blk, N) TREATING THE B BRAIN ROWS AS INDEPENDENT variables (what each
+    data-parallel rank computes for its own columns).  Pinned to clip_loss + autograd by tests/test_oracle_golden.py."""
+    B, N = Y.shape
+    col_src = torch.as_tensor(col_src, dtype=torch.long)
+    M = Zsrc.shape[0]
+    S = torch.zeros((B, M), dtype=torch.float64)
+    ysq = torch.zeros(B, dtype=torch.float64)
+    zsq = torch.zeros(M, dtype=torch.float64)
+    for c0 in range(0, N, chunk):
+        yc, zc = Y[:, c0: c0 + chunk].float(), Zsrc[:, c0: c0 + chunk].float()
+        S += (yc @ zc.T).double()
+        ysq += yc.double().pow(2).sum(dim=1)
+        zsq += zc.double().pow(2).sum(dim=1)
+    yn = ysq.sqrt()                                                   # loss.py:64-65, no eps
+    Sl = S[:, col_src].clone().requires_grad_(True)                    # (B, B) raw dot products <Y_i, Z_j>
+    zn = zsq.sqrt()[col_src].clone().requires_grad_(True)
+    t = temp.detach().double().clone().requires_grad_(True)
+    logits = Sl / (yn[:, None] * zn[None, :]) * torch.exp(t)          # loss.py:68-71
+    tgt = torch.arange(B)
+    loss = (TF.cross_entropy(logits, tgt, reduction=reduction) + TF.cross_entropy(logits.t(), tgt, reduction=reduction)) / 2
+    loss.backward()
+    out = {"loss": loss.detach(), "logits": logits.detach(), "dtemp": t.grad.detach(), "dZ": {}}
+    dS, dzn = Sl.grad, zn.grad                                         # d loss / d <Y_i, Z_j>,  d loss / d |Z_j|
+    for (j0, j1) in grad_blocks:
+        Zb = Zsrc[col_src[j0:j1]]
+        coef = (dzn[j0:j1] / zn.detach()[j0:j1]).float()               # d|Z_j| / dZ_j = Z_j / |Z_j|
+        g = torch.empty((j1 - j0, N), dtype=torch.float32)
+        W = dS[:, j0:j1].t().float().contiguous()
+        for c0 in range(0, N, chunk):
+            g[:, c0: c0 + chunk] = W @ Y[:, c0: c0 + chunk].float() + coef[:, None] * Zb[:, c0: c0 + chunk].float()
+        out["dZ"][(j0, j1)] = g
+    return out
 
 
 def topk_accuracy(Z: Tensor, Y: Tensor, k: int = 10) -> Tuple[float, float]:
@@ -309,9 +359,10 @@ def synthetic_batch(B: int, C: int, T: int, F: int, S: int, *, seed: int = 1234)
 
 
 def train_step(P: Dict[str, Tensor], temp: Tensor, X, Y, subj, *, loc, drop_centre, d_drop=0.1,
-               stats=None, reduction="mean", training=True):
+               stats=None, reduction="mean", training=True, taps=None):
     """One forward+loss+backward (train.py:187-201) on leaf copies; returns (loss, Z, logits, grads).
-    training=False: the same through an encoder in .eval() mode (BatchNorm on running statistics, no dropout)."""
+    training=False: the same through an encoder in .eval() mode (BatchNorm on running statistics, no dropout).
+    taps (tests only): dict that receives intermediate tensors with retained gradients (see subject_block)."""
     leaves = {}
     for k, v in P.items():
         if v.is_floating_point() or v.is_complex():
@@ -322,7 +373,7 @@ def train_step(P: Dict[str, Tensor], temp: Tensor, X, Y, subj, *, loc, drop_cent
     Q.update(leaves)
     t = temp.detach().clone().requires_grad_(True)
     Z = brain_encoder_forward(Q, X, subj, training=training, loc=loc, drop_centre=drop_centre,
-                              d_drop=d_drop, stats=stats)
+                              d_drop=d_drop, stats=stats, taps=taps)
     loss, logits = clip_loss(Y, Z, t, reduction)
     loss.backward()
     grads = {k: v.grad for k, v in leaves.items()}

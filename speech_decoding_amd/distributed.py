@@ -116,11 +116,15 @@ def merge_row_softmax_stats(row_max: torch.Tensor, row_sum: torch.Tensor, group=
         mine = torch.stack([p.to(torch.float32) for p in parts]).contiguous()             # (k, Bg)
         flat = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=torch.float32, device=mine.device)
         dist.all_gather_into_tensor(flat, mine, group=group)          # concatenation along dim 0, rank-major
-        allp = flat.view(world, mine.shape[0], mine.shape[1])
-        gmax = allp[:, 0].max(dim=0).values
-        row_sum = (allp[:, 1] * torch.exp(allp[:, 0] - gmax)).sum(dim=0)
-        row_max = gmax
-        if diag is not None:
-            diag = allp[:, 2].sum(dim=0)
+        return combine_row_stats(flat.view(world, mine.shape[0], mine.shape[1]))
     lse = row_max + torch.log(row_sum)
     return lse if diag is None else (lse, diag)
+
+
+def combine_row_stats(allp: torch.Tensor):
+    """The merge itself, on the gathered (world, 2 or 3, B_global) table of per-rank (max, sum exp(l - max)[, diag]) rows, in
+    rank order: lse, or (lse, diag) when the table carries the positives' logits."""
+    gmax = allp[:, 0].max(dim=0).values
+    row_sum = (allp[:, 1] * torch.exp(allp[:, 0] - gmax)).sum(dim=0)
+    lse = gmax + torch.log(row_sum)
+    return lse if allp.shape[1] < 3 else (lse, allp[:, 2].sum(dim=0))

@@ -754,7 +754,34 @@ def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: 
     """CLIP loss (loss.py:58-79) on RL embeddings: Yt holds the Bm (global) speech rows, Zt the Bn local
     brain rows.  Returns (loss_local_share, logits, ranks_count, ctx).  With `dist_group`, row statistics
     and the diagonal are merged across ranks so that the negatives span the global batch."""
-    import torch.distributed as dist
+    st = clip_block_stats(Yt, Zt, temp, Bm=Bm, Bn=Bn, T=T, col0=col0, ysq=ysq)
+    from .distributed import merge_row_softmax_stats
+    row_lse, diag = merge_row_softmax_stats(st.row_max, st.row_sum, dist_group, diag=st.diag)   # diag: zero where not owned
+    return clip_block_finish(st, row_lse, diag, reduction=reduction, B_global=B_global)
+
+
+@dataclass
+class ClipBlockStats:
+    """One rank's column block before the cross-rank merge: logits (Bm, Bn) and what the merge needs."""
+    Yt: torch.Tensor
+    Zt: torch.Tensor
+    temp: torch.Tensor
+    Bm: int
+    Bn: int
+    col0: int
+    row_elems: int
+    ysq: torch.Tensor
+    zsq: torch.Tensor
+    logits: torch.Tensor
+    row_max: torch.Tensor
+    row_sum: torch.Tensor
+    col_lse: torch.Tensor
+    diag: torch.Tensor
+
+
+def clip_block_stats(Yt, Zt, temp, *, Bm: int, Bn: int, T: int, col0: int = 0, ysq=None) -> ClipBlockStats:
+    """First half of clip_forward: norms, the (Bm x Bn) logits block of this rank's brain columns, per-row (max, sum exp)
+    over the block, per-column lse over all rows, the positives' logits.  Rank-local: no collective."""
     Fp = Zt.shape[1]
     row_elems = L.rows_tp(T) * Fp
     if ysq is None:                              # (under DP the caller gathers the per-rank norms instead)
@@ -764,8 +791,14 @@ def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: 
         zsq = ops.rows_sumsq(Zt, Bn, row_elems, row_elems)
     S = ops.matmul_nt_splitk(Yt, Zt, Bm, Bn, row_elems, row_elems)
     logits, row_max, row_sum, col_lse, diag = ops.clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0)
-    from .distributed import merge_row_softmax_stats
-    row_lse, diag = merge_row_softmax_stats(row_max, row_sum, dist_group, diag=diag)   # diag: zero where not owned
+    return ClipBlockStats(Yt, Zt, temp, Bm, Bn, col0, row_elems, ysq, zsq, logits, row_max, row_sum, col_lse, diag)
+
+
+def clip_block_finish(st: ClipBlockStats, row_lse, diag, *, reduction: str = "mean", B_global: Optional[int] = None):
+    """Second half, given the row lse over the columns of ALL ranks and the positives' logits (after the merge): this rank's
+    share of the loss and of d loss / d temp, the gradient coefficient matrix, the retrieval rank counts."""
+    Yt, Zt, temp, Bm, Bn, col0, row_elems = st.Yt, st.Zt, st.temp, st.Bm, st.Bn, st.col0, st.row_elems
+    logits, col_lse, ysq, zsq = st.logits, st.col_lse, st.ysq, st.zsq
     Bg = B_global if B_global is not None else Bm
     inv_norm = 1.0 / (2.0 * Bg) if reduction == "mean" else 0.5
     gs = G_PRESCALE.get(Yt.dtype, 1.0)

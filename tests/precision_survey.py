@@ -34,7 +34,15 @@ def survey(name, C, S, T, B, dtype, D1=270, D2=320, F=1024, K=32, last4=True, se
     scaler.scale(loss).backward()
     scaler.unscale_(list(enc.parameters()) + list(lossf.parameters()))
     Pr = operands_as_device_sees_them(P, dtype)
-    lo, Zo, _, go = O.train_step(Pr, torch.tensor([5.1]), round_to(X, dtype), round_to(Y, dtype), subj, loc=loc, drop_centre=7)
+    taps = {}
+    lo, Zo, _, go = O.train_step(Pr, torch.tensor([5.1]), round_to(X, dtype), round_to(Y, dtype), subj, loc=loc, drop_centre=7,
+                                 taps=taps)
+    # the shared 1x1 conv's bias gradient is an almost exactly cancelling sum: its error against the scale of its TERMS
+    k = "subject_block.conv.bias"
+    terms = taps["subject_block.conv.out"].grad
+    err = (grads_by_state_key(enc)[k].float().cpu() - go[k]).norm()
+    print(f"   {k}: |err| / |sqrt(sum terms^2)| = {float(err / terms.pow(2).sum(dim=(0, 2)).sqrt().norm()):.3e}   "
+          f"|err| / |sum |terms|| = {float(err / terms.abs().sum(dim=(0, 2)).norm()):.3e}   |err| / |grad| = {float(err / go[k].norm()):.3e}")
     print(f"== {name} {dtype}: Z rel_l2 {rel_l2(Z.detach().float(), Zo):.3e}  max/max {float((Z.detach().float().cpu() - Zo).abs().max() / Zo.abs().max()):.3e}"
           f"  loss {float(loss):.5f} vs {float(lo):.5f} (rel {abs(float(loss) - float(lo)) / float(lo):.2e})"
           f"  temp.grad {float(lossf.temp.grad):.5f} vs {float(go['temp']):.5f}")
@@ -50,10 +58,12 @@ def survey(name, C, S, T, B, dtype, D1=270, D2=320, F=1024, K=32, last4=True, se
 
 
 if __name__ == "__main__":
-    dts = sys.argv[1:] or ["bf16"]
+    dts = [a for a in sys.argv[1:] if not a.startswith("--")] or ["bf16"]
     for dt in dts:
         survey("small", 12, 3, 40, 6, dt, D1=16, D2=24, F=32, K=4, last4=False)
         survey("spot208-B8", 208, 27, 360, 8, dt)
         survey("spot60-B8", 60, 1, 360, 8, dt)
         survey("config5-shape-B12", 306, 100, 1000, 12, dt)
         survey("config2-B64", 208, 27, 360, 64, dt)
+        if "--full" in sys.argv:
+            survey("config2-B256", 208, 27, 360, 256, dt)

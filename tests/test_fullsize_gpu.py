@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import brain_oracle as O                                  # noqa: E402
 from tests.parity import operands_as_device_sees_them, rel_l2, round_to   # noqa: E402
-from tests.test_e2e_gpu import DTYPES16, build, grads_by_state_key, make_args, null_grad   # noqa: E402
+from tests.test_e2e_gpu import DTYPES16, build, check_lowprec_step, grads_by_state_key, make_args, null_grad   # noqa: E402
 
 DEV = "cuda:0"
 C, S, D1, D2, F, K, T, B = 208, 27, 270, 320, 1024, 32, 360, 256
@@ -92,3 +92,37 @@ def test_config2_full_batch_eval_forward_sampled_against_oracle(dtype):
 # 16-bit storage between the ~20 kernels of a forward: calibrated on tests/precision_survey.py (x ~2 margin)
 REL_EVAL = {"bf16": 4e-2, "fp16": 5e-3}
 MAX_EVAL = {"bf16": 8e-2, "fp16": 1e-2}
+
+
+def test_config2_full_batch_bf16_train_step_vs_oracle_on_rounded_operands():
+    """THE benchmarked configuration in THE benchmarked dtype (BASELINE.json configs[1]: 208 ch, batch 256, bf16): one
+    training step — embeddings, loss, temperature gradient and EVERY parameter gradient — against the oracle fed the same
+    rounded operands, with the same per-tensor bounds as the small shapes (tests/test_e2e_gpu.py)."""
+    loc, P, enc, lossf, clf, X, Y, subj = _setup("bf16")
+    report = check_lowprec_step(enc, lossf, P, [5.1], X, Y, subj, loc, 5, "bf16")
+    assert len([k for k in report if k.startswith("grad ")]) >= 40
+
+
+@pytest.mark.parametrize("name,Cc,Ss,Tt,dtype", [("configs[3] per-rank batch: 60 ch, 1 subject, batch 512", 60, 1, 360, "bf16"),
+                                                 ("configs[4] per-rank batch: 306 ch, T=1000, 100 subjects, batch 512", 306, 100, 1000, "fp16")])
+def test_other_configs_per_rank_batch_eval_forward_sampled_against_oracle(name, Cc, Ss, Tt, dtype):
+    """BASELINE.json configs[3] / configs[4] at the batch ONE rank of the 8-GPU run holds (512 segments): eval-mode forward in
+    the dtype the config names, checked on a random 8-sample subset (eval mode is per-sample independent)."""
+    Bb = 512
+    loc = O.synthetic_positions(Cc, seed=1)
+    P = O.seeded_params(Cc, Ss, D1, D2, F, K, seed=1, loc=loc)
+    args = make_args(Cc, Ss, D1, D2, 512, K, True, loc.numpy(), dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc, lossf, clf = build(args, P, [5.1])
+    X, _, subj = O.synthetic_batch(Bb, Cc, Tt, 1, Ss, seed=99)          # (the speech side is not needed here)
+    enc.eval()
+    with torch.no_grad():
+        Z = enc(X.to(DEV), subj)
+    assert tuple(Z.shape) == (Bb, F, Tt)
+    pick = torch.from_numpy(np.random.RandomState(5).choice(Bb, 8, replace=False)).sort().values
+    Zo = O.brain_encoder_forward(operands_as_device_sees_them(P, dtype), round_to(X[pick], dtype), subj[pick], training=False)
+    got = Z[pick.to(DEV)].float().cpu()
+    assert rel_l2(got, Zo) < REL_EVAL[dtype], rel_l2(got, Zo)
+    assert float((got - Zo).abs().max()) <= MAX_EVAL[dtype] * float(Zo.abs().max())
+    enc.engine.release_workspace()

@@ -1,0 +1,121 @@
+"""The loss block of the data-parallel configurations at FULL size, on one GPU.
+
+Under data parallelism every rank computes the logits block of ALL global speech rows against ITS OWN brain columns
+(`engine.clip_block_stats`), the per-row soft-max statistics are merged across ranks (`distributed.combine_row_stats`, the
+arithmetic behind the one small all-gather), and each rank then forms its share of the loss, the gradient coefficient
+matrix and the gradient of its own embeddings (`clip_block_finish`, `clip_backward`).  BASELINE.json configs[2] makes that
+block 2048 speech rows x 256 local columns with a contraction of 1024 x 360 = 368 640 per pair; configs[4] 4096 x 512 with
+1024 x 1000 = 1 024 000, in fp16.  Here the eight ranks' blocks run one after the other on the one GPU, exactly these
+sizes, and everything is compared with the CPU oracle (`oracle.clip_loss_blockwise`, pinned to the reference's CLIPLoss by
+tests/test_oracle_golden.py): logits, loss, d loss / d temp, retrieval ranks and the embedding gradients of the checked
+ranks.  The 16-bit runs feed both sides the same rounded embeddings (tests/parity.py's convention), so what is measured is
+the arithmetic of the kernels — split-K fp32 accumulation, the 16-bit coefficient matrix, the 16-bit gradient store."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import brain_oracle as O                                  # noqa: E402
+from tests.parity import rel_l2                                       # noqa: E402
+
+DEV = "cuda:0"
+TD = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+# relative L2 bound on an embedding-gradient block: the coefficient matrix G is an MFMA operand (one rounding to the compute
+# dtype per entry, independent signs) and the gradient is stored in the compute dtype (half an ulp per element)
+DZ_REL = {"fp32": 2e-5, "bf16": 6e-3, "fp16": 8e-4}
+
+
+def _free_host_gib():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:                                                 # noqa: BLE001
+        return 0.0
+
+
+@pytest.mark.parametrize("name,world,Bn,T,dtype,distinct,check", [
+    ("configs[2] 2048 x 256, T=360", 8, 256, 360, "bf16", None, (0, 5)),
+    ("configs[2] 2048 x 256, T=360, exact path", 8, 256, 360, "fp32", (2,), (2,)),
+    ("configs[4] 4096 x 512, T=1000", 8, 512, 1000, "fp16", (3,), (3,)),
+])
+def test_global_negative_loss_block_at_full_size(name, world, Bn, T, dtype, distinct, check):
+    """distinct = ranks whose brain columns are their own data (None: all); the other ranks all hold the SAME block of
+    columns (their positives still differ: rank r's column j pairs with speech row r * Bn + j), so the CPU pays for
+    len(distinct) + 1 similarity blocks instead of `world` while the GPU runs every rank's full-size block."""
+    from speech_decoding_amd import engine as E
+    from speech_decoding_amd import lib as L
+    from speech_decoding_amd import loss as sda_loss
+    from speech_decoding_amd import ops
+    from speech_decoding_amd.distributed import combine_row_stats
+    F = 1024
+    Bg, N = world * Bn, F * T
+    need_gib = (Bg + 3 * Bn) * N * 4 / 2 ** 30 * 1.25 + 4
+    if _free_host_gib() < need_gib:
+        pytest.skip(f"{name}: the CPU oracle needs ~{need_gib:.0f} GiB of host memory")
+    tdt = TD[dtype]
+    distinct = tuple(range(world)) if distinct is None else distinct
+    g = torch.Generator(device=DEV).manual_seed(1234)
+    # brain blocks: one per distinct rank + one shared by all the others; values as the device stores them
+    blocks = {r: torch.randn(Bn, F, T, generator=g, device=DEV).to(tdt) for r in (*distinct, "shared")}
+    src_of = [r if r in distinct else "shared" for r in range(world)]
+    order = list(blocks)                                               # row blocks of Zsrc on the CPU
+    col_src = torch.cat([order.index(src_of[r]) * Bn + torch.arange(Bn) for r in range(world)])
+    # speech rows correlate weakly with their positives: positives' logits ~ 3, negatives' ~ N(0, 0.3) at exp(temp) = 164 —
+    # a soft-max that is neither flat nor saturated, like a model some epochs into training
+    Y = torch.empty((Bg, F, T), dtype=tdt, device=DEV)
+    for r in range(world):
+        Y[r * Bn: (r + 1) * Bn] = (0.02 * blocks[src_of[r]].float() + torch.randn(Bn, F, T, generator=g, device=DEV)).to(tdt)
+    temp = torch.tensor([5.1], device=DEV)
+
+    # ---- the HIP path, rank by rank
+    Yt = sda_loss.as_rows(Y.float(), Bg, F, T, tdt, "Y")
+    row_elems = L.rows_tp(T) * Yt.shape[1]
+    ysq = ops.rows_sumsq(Yt, Bg, row_elems, row_elems)
+    Zt = {r: sda_loss.as_rows(b.float(), Bn, F, T, tdt, "Z") for r, b in blocks.items()}
+    stats = [E.clip_block_stats(Yt, Zt[src_of[r]], temp, Bm=Bg, Bn=Bn, T=T, col0=r * Bn, ysq=ysq) for r in range(world)]
+    row_lse, diag = combine_row_stats(torch.stack([torch.stack([s.row_max, s.row_sum, s.diag]) for s in stats]))
+    loss = torch.zeros(1, device=DEV)
+    dtemp = torch.zeros(1, device=DEV)
+    cnt = torch.zeros(Bg, dtype=torch.int32, device=DEV)
+    logits = torch.empty((Bg, Bg), dtype=torch.float32, device=DEV)
+    dZ = {}
+    one = torch.ones(1, dtype=torch.float32, device=DEV)
+    for r in range(world):
+        share, lg, c, cctx = E.clip_block_finish(stats[r], row_lse, diag, B_global=Bg)
+        loss += share
+        dtemp += cctx.dtemp
+        cnt += c
+        logits[:, r * Bn: (r + 1) * Bn] = lg
+        if r in check:
+            dZt = torch.empty((L.rows_alloc(Bn, T), Yt.shape[1]), dtype=tdt, device=DEV)
+            dZt[Bn * L.rows_tp(T):].zero_()
+            E.clip_backward(cctx, dZt, one)
+            dZ[r] = ops.rows_view(dZt, Bn, F, T).float().cpu().reshape(Bn, N)
+            assert float(dZt[: L.ROW_PAD].float().abs().max()) == 0.0          # pad rows come out as exact zeros
+    torch.cuda.synchronize()
+
+    # ---- the oracle
+    Yc = Y.cpu().float().reshape(Bg, N)
+    Zsrc = torch.cat([blocks[r].cpu().float().reshape(Bn, N) for r in order])
+    del Y, blocks
+    ref = O.clip_loss_blockwise(Yc, Zsrc, col_src, temp.cpu(), grad_blocks=[(r * Bn, (r + 1) * Bn) for r in check], chunk=16384)
+
+    assert abs(float(loss) - float(ref["loss"])) < 1e-4, (float(loss), float(ref["loss"]))
+    lg, lr = logits.cpu().double(), ref["logits"]
+    assert float((lg - lr).abs().max()) < 2e-3, float((lg - lr).abs().max())
+    assert abs(float(dtemp) - float(ref["dtemp"])) < 1e-3 * max(1.0, abs(float(ref["dtemp"]))), (float(dtemp), float(ref["dtemp"]))
+    # retrieval ranks (Classifier semantics on the logits: how many columns beat the positive); logits that differ in the
+    # last fp32 bits can swap two near-ties, so a handful of rows may be off by one
+    # (exact ties exist by construction where ranks share a column block: the lower global index wins, as in clip_ranks)
+    dref = lr.diagonal()[:, None]
+    lower = torch.arange(Bg)[None, :] < torch.arange(Bg)[:, None]
+    want = ((lr > dref) | ((lr == dref) & lower)).sum(dim=1)
+    got = cnt.cpu().long()
+    assert float((got != want).double().mean()) < 5e-3 and int((got - want).abs().max()) <= 1
+    assert float((got < 10).double().mean()) == pytest.approx(float((want < 10).double().mean()), abs=2e-3)
+    for r in check:
+        want_dz = ref["dZ"][(r * Bn, (r + 1) * Bn)]
+        err = rel_l2(dZ[r], want_dz)
+        assert err < DZ_REL[dtype], (name, r, err)
+        assert float((dZ[r] - want_dz).abs().max()) <= 40 * DZ_REL[dtype] * float(want_dz.abs().max()), (name, r)

@@ -179,3 +179,25 @@ def test_full_dimension_spot_checks(tag, C, S):
     for k in stats:
         if "running" in k:
             np.testing.assert_allclose(stats[k].numpy(), s["after1fwd/" + k], rtol=1e-4, atol=1e-5)
+
+
+def test_blockwise_loss_oracle_equals_the_pinned_one():
+    """oracle.clip_loss_blockwise (the chunked form the full-size loss-block tests need) against clip_loss + autograd, which the
+    fixtures above pin to the reference: loss, logits, temperature gradient and embedding gradients, with distinct columns and
+    with a repeated column block."""
+    g = torch.Generator().manual_seed(3)
+    B, N = 12, 700
+    Y = torch.randn(B, N, generator=g)
+    temp = torch.tensor([2.3])
+    for col_src, Zsrc in (([*range(B)], 0.3 * Y + torch.randn(B, N, generator=g)),
+                          ([0, 1, 2, 3] * 3, 0.3 * Y[:4] + torch.randn(4, N, generator=g))):
+        Z = Zsrc[col_src].clone().requires_grad_(True)
+        t = temp.clone().requires_grad_(True)
+        loss, logits = O.clip_loss(Y.view(B, 7, 100), Z.view(B, 7, 100), t)
+        loss.backward()
+        got = O.clip_loss_blockwise(Y, Zsrc, col_src, temp, grad_blocks=[(0, 4), (4, 12)], chunk=256)
+        assert abs(float(got["loss"]) - float(loss)) < 1e-6
+        np.testing.assert_allclose(got["logits"].numpy(), logits.detach().numpy(), rtol=1e-5, atol=1e-5)
+        assert abs(float(got["dtemp"]) - float(t.grad)) < 1e-5
+        for (j0, j1), dz in got["dZ"].items():
+            np.testing.assert_allclose(dz.numpy(), Z.grad[j0:j1].numpy(), rtol=1e-4, atol=1e-7)
