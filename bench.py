@@ -217,7 +217,8 @@ def main():
     from speech_decoding_amd.optim import FusedAdam        # same rule as torch.optim.Adam, one launch
     opt = FusedAdam(params, lr=float(cfg.lr))
     from speech_decoding_amd.amp import LossScaler
-    scaler = LossScaler.for_dtype(enc.compute_dtype)        # static loss scale for fp16; a no-op for bf16 / fp32
+    scaler = LossScaler.for_dtype(enc.compute_dtype, global_batch=a.batch * world, T=T)   # static loss scale for fp16 (grows with
+                                                                                           # the global batch); a no-op for bf16 / fp32
 
     # synthetic data pool resident in HBM: X ~ N(0,1) clamped ±20; Y = P·X + 0.5·eps (learnable structure).
     # Subject indices are drawn FRESH every step (as a data loader delivers them), so the per-step index uploads are real.

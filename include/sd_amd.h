@@ -162,7 +162,8 @@ int sda_conv_stats_rows(int B, int T, int KS, int Cout_p, int flags);
 int sda_bn_finalize(const float* partial, int ntiles, double count, const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean, float* running_var, float* mean,
                     float* rstd, float* scale, float* shift, float* bwd_coef /* optional [4][Cp]: gamma, beta,
-                    mean, rstd for sda_conv_args.bn_coef */, int C, int Cp, int training, void* stream);
+                    mean, rstd for sda_conv_args.bn_coef */, int C, int Cp, int training,
+                    long* batches_tracked /* optional: the module's num_batches_tracked, += 1 in training mode */, void* stream);
 /* y = GELU(x * scale[c] + shift[c]) on valid rows */
 int sda_bn_gelu_forward(const void* x, void* y, const float* scale, const float* shift, int B, int T,
                         int Cp, int dtype, void* stream);
@@ -189,6 +190,12 @@ int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean,
                                int B, int T, int Cp, int dtype, void* stream);
 int sda_reduce_scratch_floats(int Cp);
 
+/* Zero the rows of an RL buffer that kernels never write: the SDA_ROW_PAD rows in front of each of the B samples and the
+ * slack behind the last one (a buffer whose valid rows a kernel is about to fill needs nothing else initialised) */
+int sda_zero_pad_rows(void* buf, int B, int T, int Cp, int dtype, void* stream);
+/* out[i] = a[i] * b[0], i < n (device scalars: e.g. d loss / d temp times the incoming gradient) */
+int sda_scalar_mul(const float* a, const float* b, float* out, int n, void* stream);
+
 /* GLU over channels: y[:, c] = x[:, c] * sigmoid(x[:, Ch + c]), x has 2*Ch channels (models.py:164) */
 int sda_glu_forward(const void* x, void* y, int B, int T, int Ch, int dtype, void* stream);
 int sda_glu_backward(const void* x, const void* dy, void* dx, int B, int T, int Ch, int dtype, void* stream);
@@ -214,7 +221,7 @@ int sda_colsum(const void* x, float* out, float* scratch /* sda_reduce_scratch_f
 /* Weight-gradient GEMM:  g[seg][tap][co][ci] = sum_{b in seg} sum_t dy[b,t,co] * x[b, t+(tap-KS/2)*dil, ci]
  * Samples are visited through `perm` (device int32 [B]); segment s covers perm[seg_start[s]..seg_start[s+1]).
  * Output fp32 slabs [nseg][KS][Cout_p][Cin_p].  With out_e != NULL (KS must be 1, nseg 1) the result is
- * written as `dtype` rows instead:  out_e[co][ci] = acc - rscale[co] * sub[co][ci]   (loss backward dZ). */
+ * written as `dtype` rows instead:  out_e[co][ci] = out_scale * (acc_scale[co] * acc - rscale[co] * sub[co][ci])   (loss backward dZ). */
 typedef struct sda_wgrad_args {
   const void* dy;       /* RL [rows][dy_pitch] */
   const void* x;        /* RL [rows][x_pitch] */
@@ -232,6 +239,7 @@ typedef struct sda_wgrad_args {
   long dy_zero_row;       /* index of a row of dy that is all zero (row 0 of any RL buffer); stands in for t >= T */
   int co_valid;           /* rows of out_e to write (out_e mode) */
   int dtype;
+  const float* acc_scale; /* optional [Cout]: multiplies the fp32 accumulator of typed-output row co before `sub` is taken off */
 } sda_wgrad_args;
 int sda_wgrad_gemm(const sda_wgrad_args* a, void* stream);
 /* dst[i] = sum_s src[s][i] in fixed order */
@@ -264,18 +272,41 @@ int sda_sa_weights_backward(const float* dWd, const float* W, const float* mask,
  * Multi-GPU: rows are global (Bm), columns are this rank's Bn samples starting at global index col0;
  * zsq holds the Bn local norms. */
 int sda_clip_logits_stats(const float* S, long s_pitch, const float* ysq, const float* zsq, const float* temp,
-                          float* logits, float* row_max, float* row_sum, float* col_lse, float* diag,
+                          float* logits, float* row_max, float* row_sum, float* col_lse, float* diag /* every row written: 0 where
+                          the positive lives elsewhere */, float* row_lse /* optional: max + log(sum) of the local block */,
                           int Bm, int Bn, int col0, void* stream);
-/* Given the final row lse (after any cross-rank merge): D = dloss/dlogits, G[i][j] = D * exp(temp) /
- * (|Y_i||Z_j|) stored as `dtype` with pitch g_pitch, rscale[j] = sum_i D_ij logits_ij / |Z_j|^2,
- * scalars[0] = this block's share of the loss, scalars[1] = its share of dloss/dtemp.
- * inv_norm = 1/(2*B_global) for reduction="mean", 1/2 for "sum".  colpart: 2*Bn floats of scratch. */
+/* Given the final row lse (after any cross-rank merge), with D_ij = p_row + p_col - 2 delta (dloss/dlogits = inv_norm * D):
+ * G[i][j] = D_ij * ymax / |Y_i| (ymax = max_i |Y_i|: O(1) entries, safe in 16-bit) stored as `dtype` with pitch g_pitch —
+ * [Bm + 1][g_pitch], the extra row and the columns >= Bn are written as zeros —, cscale[j] = inv_norm * exp(temp) /
+ * (ymax |Z_j|) (the factor taken out of G: sda_wgrad_args.acc_scale of the dZ product), rscale[j] = inv_norm * sum_i D_ij
+ * logits_ij / |Z_j|^2, so that dZ_j = cscale_j * sum_i G_ij Y_i - rscale_j Z_j; scalars[0] = this block's share of the loss,
+ * scalars[1] = its share of dloss/dtemp.  inv_norm = 1/(2*B_global) for reduction="mean", 1/2 for "sum".  colpart: 2*Bn floats. */
 int sda_clip_grad(const float* logits, const float* row_lse, const float* col_lse, const float* ysq,
                   const float* zsq, const float* temp, float inv_norm, int col0, void* G, long g_pitch,
-                  float* rscale, float* colpart, float* scalars, int Bm, int Bn, int dtype, void* stream);
+                  float* rscale, float* cscale, float* colpart, float* scalars, int Bm, int Bn, int dtype, void* stream);
 /* cnt[i] = #{local j : logits[i][j] beats diag[i]} (ties: lower global index wins) — Classifier ranks */
 int sda_clip_ranks(const float* logits, const float* diag, int32_t* cnt, int Bm, int Bn, int col0, void* stream);
 int sda_device_count(void);
+
+/* Batched fp32 matrix product on parameter-sized operands with arbitrary element strides (exact-fp32 MFMA):
+ *     C[b][i][j] = sum_{k < K} A[b][i][k] * B[b][k][j],    i < M, j < N, b < batch
+ * with A[b][i][k] at A + b * a_b + i * a_i + k * a_k (B, C alike).  Nothing needs padding or alignment.  C is written as
+ * c_dtype (SDA_F32 / SDA_BF16 / SDA_F16); elements outside [0, M) x [0, N) are not touched.  Replaces the parameter-space
+ * products of the composed SubjectBlock (models.py:111-117: W_subj[s] . (W_sb . W_sa | b_sb)) and of its chain rule. */
+typedef struct sda_pgemm_args {
+  const float* A;
+  const float* B;
+  void* C;
+  int M, N, K, batch;
+  long a_i, a_k, a_b;
+  long b_k, b_j, b_b;
+  long c_i, c_j, c_b;
+  int c_dtype;
+} sda_pgemm_args;
+int sda_param_gemm(const sda_pgemm_args* a, void* stream);
+/* dst[i * d0 + j * d1 + k * d2] = src[i * s0 + j * s1 + k * s2] for (i, j, k) < (n0, n1, n2): fp32, element strides */
+int sda_copy3d(float* dst, long d0, long d1, long d2, const float* src, long s0, long s1, long s2, int n0, int n1, int n2,
+               void* stream);
 /* Asynchronous upload of a small host table (nwords 32-bit words) carried in kernel arguments: no memcpy, no
  * host<->stream synchronisation. The host buffer is read before the call returns. */
 int sda_upload_words(void* dst, const void* src_host, long nwords, void* stream);

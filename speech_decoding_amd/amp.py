@@ -21,6 +21,17 @@ import torch
 DEFAULT_FP16_SCALE = 1024.0
 
 
+def fp16_scale_for(global_batch: int, T: int, base: float = DEFAULT_FP16_SCALE, ref_batch: int = 256, ref_T: int = 360) -> float:
+    """Static fp16 loss scale for a run with `global_batch` segments of `T` samples.  The gradient that enters the encoder is
+    ~ exp(temp) / (2 B_global |Y| |Z|) with norms ~ sqrt(F T), i.e. it shrinks like 1 / (B_global T): 9e-7 at batch 256 x 360
+    samples (where `base` = 1024 puts it at 9e-4), 2e-8 at BASELINE configs[4]'s 4096 x 1000 — below fp16's smallest
+    subnormal (6e-8) unscaled and still subnormal at 1024.  Scaled by the same power of two the gradients stay where the
+    calibration left them; parameter gradients are fp32 and are un-scaled before the optimiser sees them."""
+    import math
+    f = max(1.0, global_batch / ref_batch) * max(1.0, T / ref_T)
+    return min(float(base) * 2.0 ** math.ceil(math.log2(f)), 2.0 ** 24)
+
+
 class LossScaler:
     def __init__(self, scale: float = 1.0, growth_interval: int = 2000):
         self.scale_value = float(scale)
@@ -29,8 +40,11 @@ class LossScaler:
         self.skipped_steps = 0
 
     @classmethod
-    def for_dtype(cls, dtype: torch.dtype, scale: float = DEFAULT_FP16_SCALE) -> "LossScaler":
-        return cls(scale if dtype == torch.float16 else 1.0)
+    def for_dtype(cls, dtype: torch.dtype, scale: float = DEFAULT_FP16_SCALE, global_batch: int = 0, T: int = 0) -> "LossScaler":
+        """fp16: `scale`, or with (global_batch, T) given the scale fp16_scale_for() derives from them; other dtypes: a no-op."""
+        if dtype != torch.float16:
+            return cls(1.0)
+        return cls(fp16_scale_for(global_batch, T, scale) if global_batch and T else scale)
 
     def scale(self, loss: torch.Tensor) -> torch.Tensor:
         return loss if self.scale_value == 1.0 else loss * self.scale_value

@@ -328,7 +328,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* mean_o,
                                    float* rstd_o, float* scale_o, float* shift_o, float* bwd_coef, int C, int Cp,
-                                   int training) {
+                                   int training, long* batches_tracked) {
+  // nn.BatchNorm1d.num_batches_tracked += 1 (models.py:135,143: track_running_stats) — here, not in a launch of its own
+  if (batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double s = 0.0, q = 0.0;
   if (training) block_partial_sums(partial, ntiles, Cp, blockIdx.x * 8, true, s, q);
@@ -777,6 +779,40 @@ using namespace sda;
     else { set_error("unknown dtype %d", (int)(dtype)); return -1; } \
   } while (0)
 
+namespace sda {
+// rows of a row-layout buffer that no kernel writes but every conv reads as zeros: the PAD rows in front of each sample and
+// the slack behind the last one (16-byte stores; a row is Cp * sizeof(E) bytes, a multiple of 128)
+__global__ __launch_bounds__(256) void zero_pad_rows_kernel(uint4* __restrict__ buf, int B, int Tp, long rows_alloc, int row_vec) {
+  const long pad_vecs = (long)B * PAD * row_vec, tail_vecs = (rows_alloc - (long)B * Tp) * row_vec;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pad_vecs + tail_vecs; i += (long)gridDim.x * 256) {
+    long v;
+    if (i < pad_vecs) { const long b = i / ((long)PAD * row_vec), r = i - b * PAD * row_vec; v = b * Tp * row_vec + r; }
+    else v = (long)B * Tp * row_vec + (i - pad_vecs);
+    buf[v] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+__global__ void scalar_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] * b[0];
+}
+}  // namespace sda
+
+extern "C" int sda_zero_pad_rows(void* buf, int B, int T, int Cp, int dtype, void* stream) {
+  if (!buf || B < 1 || T < 1 || Cp % 64) { set_error("zero_pad_rows: bad arguments"); return -1; }
+  const int row_vec = Cp * (dtype == SDA_F32 ? 4 : 2) / 16;
+  const long n = ((long)B * PAD + (rows_alloc(B, T) - (long)B * rows_tp(T))) * row_vec;
+  const long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(zero_pad_rows_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream,
+                     (uint4*)buf, B, rows_tp(T), rows_alloc(B, T), row_vec);
+  return check_launch("zero_pad_rows");
+}
+
+extern "C" int sda_scalar_mul(const float* a, const float* b, float* out, int n, void* stream) {
+  if (!a || !b || !out || n < 1) { set_error("scalar_mul: bad arguments"); return -1; }
+  hipLaunchKernelGGL(scalar_mul_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, b, out, n);
+  return check_launch("scalar_mul");
+}
+
 extern "C" int sda_pack_rows(const float* src, void* dst, int B, int C, int T, int Cp, int dtype, void* stream) {
   if (!src || !dst || Cp % 64 || C > Cp || B < 1) { set_error("pack_rows: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
@@ -920,13 +956,13 @@ extern "C" int sda_unpack_vector(const float* g, float* dst, int C, int Cp, int 
 extern "C" int sda_bn_finalize(const float* partial, int ntiles, double count, const float* gamma, const float* beta,
                                float eps, float momentum, float* running_mean, float* running_var, float* mean,
                                float* rstd, float* scale, float* shift, float* bwd_coef, int C, int Cp, int training,
-                               void* stream) {
+                               long* batches_tracked, void* stream) {
   if (!gamma || !beta || !mean || !rstd || !scale || !shift || C > Cp) { set_error("bn_finalize: bad arguments"); return -1; }
   if (training && (!partial || ntiles < 1 || count < 1.0)) { set_error("bn_finalize: training mode needs partial statistics"); return -1; }
   if (!training && (!running_mean || !running_var)) { set_error("bn_finalize: eval mode needs running statistics"); return -1; }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, ntiles, count,
                      gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, bwd_coef, C, Cp,
-                     training);
+                     training, training ? batches_tracked : nullptr);
   return check_launch("bn_finalize");
 }
 

@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void sa_softmax_bwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void clip_rows_kernel(const float* __restrict__ S, long s_pitch, const float* __restrict__ ysq,
                                                         const float* __restrict__ zsq, const float* __restrict__ temp,
                                                         float* __restrict__ logits, float* __restrict__ row_max,
-                                                        float* __restrict__ row_sum, float* __restrict__ diag, int Bm, int Bn,
-                                                        int col0) {
+                                                        float* __restrict__ row_sum, float* __restrict__ diag,
+                                                        float* __restrict__ row_lse, int Bm, int Bn, int col0) {
   __shared__ float sh[4];
   const int i = blockIdx.x, tid = threadIdx.x;
   const float alpha = expf(temp[0]);
@@ -174,7 +174,11 @@ __global__ __launch_bounds__(256) void clip_rows_kernel(const float* __restrict_
   float sum = 0.f;
   for (int j = tid; j < Bn; j += 256) sum += expf(logits[(size_t)i * Bn + j] - mx);
   sum = block_sum(sum, sh);
-  if (tid == 0) { row_max[i] = mx; row_sum[i] = sum; }
+  if (tid == 0) {
+    row_max[i] = mx; row_sum[i] = sum;
+    if (row_lse) row_lse[i] = mx + logf(sum);              // the row's lse over THIS block of columns (all of them on one GPU)
+    if (i < col0 || i >= col0 + Bn) diag[i] = 0.f;         // the positive lives in another rank's block
+  }
 }
 
 // block per local column j: lse over all rows
@@ -191,32 +195,47 @@ __global__ __launch_bounds__(256) void clip_cols_kernel(const float* __restrict_
   if (tid == 0) col_lse[j] = mx + logf(sum);
 }
 
-// block per local column j: D_ij, G_ij, r_j and the per-column scalar partials
+// block per local column j: D_ij, G_ij, r_j, the GEMM epilogue's column factor and the per-column scalar partials.
+// G is an MFMA operand of the dZ product, i.e. it is stored in the compute dtype — and dL/dlogits * exp(temp) / (|Y_i||Z_j|)
+// is ~1e-8 at the 8-GPU shapes (1 / (2 B_global) times 164 over norms of ~1000 each): far below fp16's range.  What is
+// stored is therefore the O(1) part,  G[i][j] = (p_row + p_col - 2 delta_ij) * (ymax / |Y_i|),  ymax = max_i |Y_i|, and what
+// was taken out,  cscale[j] = inv_norm * exp(temp) / (ymax |Z_j|),  multiplies the fp32 accumulator of column j's
+// gradient in the GEMM's epilogue:  dZ_j = cscale_j * sum_i G_ij Y_i - rscale_j Z_j.
 template <typename E>
 __global__ __launch_bounds__(256) void clip_grad_kernel(const float* __restrict__ logits, const float* __restrict__ row_lse,
                                                         const float* __restrict__ col_lse, const float* __restrict__ ysq,
                                                         const float* __restrict__ zsq, const float* __restrict__ temp,
                                                         float inv_norm, int col0, E* __restrict__ G, long g_pitch,
-                                                        float* __restrict__ rscale, float* __restrict__ colpart, int Bm,
-                                                        int Bn) {
+                                                        float* __restrict__ rscale, float* __restrict__ cscale,
+                                                        float* __restrict__ colpart, int Bm, int Bn) {
   __shared__ float sh[4];
   const int j = blockIdx.x, tid = threadIdx.x;
+  // G has one all-zero row behind the Bm real ones (the dZ GEMM's stand-in for rows past the batch) and zero padding columns
+  // up to g_pitch: written here, so the caller hands in an uninitialised buffer
+  if (tid == 0) Elem<E>::st(G + (size_t)Bm * g_pitch + j, 0.f);
+  if (j >= Bn) {
+    for (int i = tid; i < Bm; i += 256) Elem<E>::st(G + (size_t)i * g_pitch + j, 0.f);
+    return;
+  }
+  float ymax2 = 0.f;
+  for (int i = tid; i < Bm; i += 256) ymax2 = fmaxf(ymax2, ysq[i]);
+  ymax2 = block_max(ymax2, sh);
+  const float ymax = sqrtf(ymax2);
   const float alpha = expf(temp[0]);
   const float cl = col_lse[j];
-  const float mj = alpha / sqrtf(zsq[j]);
   float dl = 0.f;
   for (int i = tid; i < Bm; i += 256) {
     const float l = logits[(size_t)i * Bn + j];
     float d = expf(l - row_lse[i]) + expf(l - cl);
     if (i == col0 + j) d -= 2.f;
-    d *= inv_norm;
     dl += d * l;
-    Elem<E>::st(G + (size_t)i * g_pitch + j, d * mj / sqrtf(ysq[i]));
+    Elem<E>::st(G + (size_t)i * g_pitch + j, d * (ymax / sqrtf(ysq[i])));
   }
-  dl = block_sum(dl, sh);
+  dl = block_sum(dl, sh) * inv_norm;
   if (tid == 0) {
     const float ljj = logits[(size_t)(col0 + j) * Bn + j];
     rscale[j] = dl / zsq[j];
+    cscale[j] = inv_norm * alpha / (ymax * sqrtf(zsq[j]));
     colpart[j * 2 + 0] = (row_lse[col0 + j] - ljj) + (cl - ljj);   // both CE terms of sample (col0 + j)
     colpart[j * 2 + 1] = dl;                                       // d loss / d temp share
   }
@@ -309,30 +328,31 @@ extern "C" int sda_sa_weights_backward(const float* dWd, const float* W, const f
 }
 
 extern "C" int sda_clip_logits_stats(const float* S, long s_pitch, const float* ysq, const float* zsq, const float* temp,
-                                     float* logits, float* row_max, float* row_sum, float* col_lse, float* diag, int Bm,
-                                     int Bn, int col0, void* stream) {
+                                     float* logits, float* row_max, float* row_sum, float* col_lse, float* diag,
+                                     float* row_lse, int Bm, int Bn, int col0, void* stream) {
   if (!S || !ysq || !zsq || !temp || !logits || !row_max || !row_sum || !col_lse || !diag || Bm < 1 || Bn < 1) {
     set_error("clip_logits_stats: bad arguments"); return -1;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(clip_rows_kernel, dim3(Bm), dim3(256), 0, st, S, s_pitch, ysq, zsq, temp, logits, row_max, row_sum, diag, Bm, Bn, col0);
+  hipLaunchKernelGGL(clip_rows_kernel, dim3(Bm), dim3(256), 0, st, S, s_pitch, ysq, zsq, temp, logits, row_max, row_sum, diag, row_lse, Bm, Bn, col0);
   hipLaunchKernelGGL(clip_cols_kernel, dim3(Bn), dim3(256), 0, st, logits, col_lse, Bm, Bn);
   return check_launch("clip_logits_stats");
 }
 
 extern "C" int sda_clip_grad(const float* logits, const float* row_lse, const float* col_lse, const float* ysq,
                              const float* zsq, const float* temp, float inv_norm, int col0, void* G, long g_pitch,
-                             float* rscale, float* colpart, float* scalars, int Bm, int Bn, int dtype, void* stream) {
-  if (!logits || !row_lse || !col_lse || !ysq || !zsq || !temp || !G || !rscale || !colpart || !scalars) {
-    set_error("clip_grad: null argument"); return -1;
+                             float* rscale, float* cscale, float* colpart, float* scalars, int Bm, int Bn, int dtype,
+                             void* stream) {
+  if (!logits || !row_lse || !col_lse || !ysq || !zsq || !temp || !G || !rscale || !cscale || !colpart || !scalars || g_pitch < Bn) {
+    set_error("clip_grad: null argument or g_pitch < Bn"); return -1;
   }
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SDA_F32)
-    hipLaunchKernelGGL(clip_grad_kernel<float>, dim3(Bn), dim3(256), 0, st, logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, (float*)G, g_pitch, rscale, colpart, Bm, Bn);
+    hipLaunchKernelGGL(clip_grad_kernel<float>, dim3((unsigned)g_pitch), dim3(256), 0, st, logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, (float*)G, g_pitch, rscale, cscale, colpart, Bm, Bn);
   else if (dtype == SDA_BF16)
-    hipLaunchKernelGGL(clip_grad_kernel<uint16_t>, dim3(Bn), dim3(256), 0, st, logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, (uint16_t*)G, g_pitch, rscale, colpart, Bm, Bn);
+    hipLaunchKernelGGL(clip_grad_kernel<uint16_t>, dim3((unsigned)g_pitch), dim3(256), 0, st, logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, (uint16_t*)G, g_pitch, rscale, cscale, colpart, Bm, Bn);
   else if (dtype == SDA_F16)
-    hipLaunchKernelGGL(clip_grad_kernel<half_t>, dim3(Bn), dim3(256), 0, st, logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, (half_t*)G, g_pitch, rscale, colpart, Bm, Bn);
+    hipLaunchKernelGGL(clip_grad_kernel<half_t>, dim3((unsigned)g_pitch), dim3(256), 0, st, logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, (half_t*)G, g_pitch, rscale, cscale, colpart, Bm, Bn);
   else { set_error("clip_grad: unknown dtype"); return -1; }
   hipLaunchKernelGGL(clip_scalars_kernel, dim3(1), dim3(64), 0, st, colpart, inv_norm, scalars, Bn);
   return check_launch("clip_grad");

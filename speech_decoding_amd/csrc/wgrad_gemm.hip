@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
     return;
   }
 
-  // typed output through LDS: out[co][ci] = acc - rscale[co] * sub[co][ci]   (KS == 1)
+  // typed output through LDS: out[co][ci] = out_scale * (acc_scale[co] * acc - rscale[co] * sub[co][ci])   (KS == 1)
   constexpr int EP_STRIDE = WG_TN + 4;
   float* ep = reinterpret_cast<float*>(smem);
   __syncthreads();
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
     if (co >= a.co_valid) continue;
     float4 v = *reinterpret_cast<const float4*>(ep + row * EP_STRIDE + c4 * 4);
     const size_t off = (size_t)co * a.out_pitch + ci0 + c4 * 4;
+    if (a.acc_scale) { const float cs = a.acc_scale[co]; v.x *= cs; v.y *= cs; v.z *= cs; v.w *= cs; }
     if (sg) {
       const float rs = a.rscale[co];
       const float4 s = load4(sg + off);

@@ -104,8 +104,6 @@ class EncoderEngine:
                                              # (needs the fused forward: bufs hold (out, gate)); not with flat-tile data gradients.
                                              # Off: measured 7.87 vs 7.77 ms — the separate pass is HBM-bound and runs beside the
                                              # weight-gradient stream's MFMA work for free, the heavier conv epilogue does not
-        self.chain_rule_bf16 = False         # 16-bit modes: the chain rule's parameter-space products on bf16 operands (see _mm);
-                                             # measured: no gain in the step (7.64 vs 7.59 ms), so the fp32 products stay
         self.skip_x0_gradient = True         # composed SubjectBlock: its weight gradient straight from block 0's dh0 and X (kernel-3
                                              # per-subject weight gradient + chain rule) instead of conv0's data gradient + dx0 (x) X
         self.compose_subject_block = True    # SpatialAttention, the shared 1x1 conv and the per-subject 1x1 conv as ONE per-subject
@@ -195,14 +193,6 @@ class EncoderEngine:
     @property
     def glu_fused(self) -> bool:
         return bool(self.fuse_glu_forward and self.flat_tiles_forward and self.d.D2p % 80 == 0)
-
-    def _mm(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-        """Parameter-space product of the composed SubjectBlock's chain rule.  fp32 mode: fp32 (the exact path).  16-bit modes:
-        optionally (chain_rule_bf16) bf16 operands with fp32 accumulation, like every other weight gradient of those modes — the fp32
-        library GEMMs of these shapes run at ~30 TFLOP/s on the step's tail, but the step did not get shorter without them."""
-        if self.dtype == torch.float32 or not self.chain_rule_bf16:
-            return a @ b
-        return (a.to(torch.bfloat16) @ b.to(torch.bfloat16)).float()
 
     def _wait(self, label: str, stream, event):
         """stream.wait_event(event); with a probe attached, bracketed by timing events (how long the stream sat idle)."""
@@ -335,22 +325,27 @@ class EncoderEngine:
 
         # ---- SubjectBlock (models.py:111-117)
         bufs["Xt"] = Xt
-        W_sa, Wp = ops.sa_weights_forward(P["z"], P["cos"], P["sin"], mask, d.D1p, d.Cp, dt, fwd_table=P.get("sa_tab_f"))
+        # (composed SubjectBlock: the SpatialAttention weights are wanted in fp32 — the "packed operand" W * mask then IS the
+        # fp32 matrix the composition below multiplies)
+        W_sa, Wp = ops.sa_weights_forward(P["z"], P["cos"], P["sin"], mask, d.D1p, d.Cp, torch.float32 if composed else dt,
+                                          fwd_table=P.get("sa_tab_f"))
         ctx.W_sa = W_sa
         if composed:
             # models.py:111-117 is three linear maps in a row with nothing between them: x0 = W_subj[s] (W_sb (W_sa X) + b_sb).
             # Composed per subject in fp32 parameter space — (S, D1, C + 1) with the bias riding on Xt's constant channel —
             # one per-sample-weight GEMM replaces three, and the backward needs no data gradient at all here (X is an input):
-            # one per-subject weight gradient, then the chain rule on (S, D1, C)-sized matrices (plain library GEMMs).
-            Wd = W_sa if mask is None else W_sa * mask
-            Ws = P["subj_w"][..., 0]                                                             # (S, D1, D1)
-            T1aug = torch.cat([P["sb_w"][..., 0] @ Wd, P["sb_b"][:, None]], dim=1)            # (D1, C + 1)
+            # one per-subject weight gradient, then the chain rule on (S, D1, C)-sized matrices.  All of these small products
+            # run on ops.param_gemm (exact-fp32 MFMA on strided views: no padding, packing, cat or copy around them).
+            Wd = Wp[0, 0, : d.D1, : d.C]                                                         # W_sa * mask, (D1, C) view
+            Ws = P["subj_w"][..., 0]                                                             # (S, D1, D1) view
+            T1aug = torch.empty((d.D1, d.C + 1), dtype=torch.float32, device=dev)               # [W_sb W_d | b_sb]
+            ops.param_gemm(P["sb_w"][..., 0], Wd, out=T1aug[:, : d.C])
+            ops.copy3d(T1aug[:, d.C:], P["sb_b"][:, None])
             key = ("wtot", str(dev), dt)
             Wtot = self._const.get(key)
             if Wtot is None:
                 Wtot = self._const[key] = torch.zeros((d.S, 1, d.D1p, d.Cp), dtype=dt, device=dev)
-            # (all subjects in ONE (S D1 x D1) . (D1 x C+1) product: the batched form picks a much slower library kernel)
-            Wtot[:, 0, : d.D1, : d.C + 1].copy_((Ws.reshape(d.S * d.D1, d.D1) @ T1aug).view(d.S, d.D1, d.C + 1))
+            ops.param_gemm(Ws, T1aug, out=Wtot[:, 0, : d.D1, : d.C + 1])                      # rounded to the compute dtype on the way out
             if need_grad:
                 ctx.composed = (Wd, T1aug, Ws)
             if packed_ready is not None:
@@ -394,7 +389,7 @@ class EncoderEngine:
                         nt = 1
                     mean, rstd, scale, shift, bcoef = ops.bn_finalize(stats, nt, count, P[bnp + "w"], P[bnp + "b"],
                                                                       P[bnp + "rm"], P[bnp + "rv"], d.D2p, True, eps, momentum,
-                                                                      want_bwd_coef=True)
+                                                                      want_bwd_coef=True, batches_tracked=P.get(bnp + "nbt"))
                 else:
                     ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, alg_dims=alg, flags=k3_flags)
                     # (the backward coefficient table only when a backward may follow: eval-mode BatchNorm is then a fixed
@@ -581,7 +576,9 @@ class EncoderEngine:
         flush(["f2w", "f2b", "f1w", "f1b"])
 
         # ---- ConvBlocks, last to first
-        null_bias = torch.zeros((10, d.D2), dtype=torch.float32, device=dev)
+        null_bias = self._const.get(("null_bias", str(dev)))      # (never written: handed out as the gradient of biases that have none)
+        if null_bias is None:
+            null_bias = self._const[("null_bias", str(dev))] = torch.zeros((10, d.D2), dtype=torch.float32, device=dev)
         flip = 0
         for k in range(4, -1, -1):
             cin, cin_p = (d.D1, d.D1p) if k == 0 else (d.D2, d.D2p)
@@ -664,22 +661,25 @@ class EncoderEngine:
                                    seg_start=ctx.subj_seg, nseg=r * d.S)     # (r*S, 3, D2p, Cp); column C: the folded bias
                 if r > 1:
                     M = ops.reduce_slabs(M.view(r, -1))
-                W0cat = torch.zeros((d.D1, 3, d.D2p), dtype=torch.float32, device=dev)
-                W0cat[:, :, : d.D2] = P["b0.c0w"].permute(1, 2, 0)                                 # [d][tap][o]
-                G = self._mm(W0cat.view(d.D1, 3 * d.D2p), M.view(d.S, 3 * d.D2p, d.Cp))[:, :, : d.C + 1]        # (S, D1, C + 1)
+                key = ("w0cat", str(dev))
+                W0cat = self._const.get(key)             # [d][tap][o], o zero-padded to D2p (the padding is written once)
+                if W0cat is None:
+                    W0cat = self._const[key] = torch.zeros((d.D1, 3, d.D2p), dtype=torch.float32, device=dev)
+                ops.copy3d(W0cat[:, :, : d.D2], P["b0.c0w"].permute(1, 2, 0))
+                G = ops.param_gemm(W0cat.view(d.D1, 3 * d.D2p), M.view(d.S, 3 * d.D2p, d.Cp)[:, :, : d.C + 1])   # (S, D1, C + 1)
             else:
                 slabs = ops.wgrad_gemm(dhs, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg,
                                        nseg=r * d.S)                    # (r*S, 1, D1p, Cp): dL/dW_tot[s], column C = dL/db_tot[s]
                 if r > 1:
                     slabs = ops.reduce_slabs(slabs.view(r, -1))
-                G = slabs.view(d.S, d.D1p, d.Cp)[:, : d.D1, : d.C + 1]                            # (S, D1, C + 1)
-            G2 = G.reshape(d.S * d.D1, d.C + 1)            # (one 2-D product each instead of S small ones: see forward)
-            grads["subj_w"] = self._mm(G2, T1aug.t()).view(d.S, d.D1, d.D1, 1)                 # W_tot = W_subj T1aug
-            dT1 = self._mm(Ws.reshape(d.S * d.D1, d.D1).t(), G2)                                 # sum_s W_subj[s]^T G[s]
-            grads["sb_b"] = dT1[:, d.C].contiguous()
+                G = slabs.view(d.S, d.D1p, d.Cp)[:, : d.D1, : d.C + 1]                            # (S, D1, C + 1) view
+            grads["subj_w"] = ops.param_gemm(G, T1aug.t()).view(d.S, d.D1, d.D1, 1)            # W_tot[s] = W_subj[s] T1aug
+            part = ops.param_gemm(Ws.transpose(1, 2), G)                                         # W_subj[s]^T G[s] per subject ...
+            dT1 = ops.reduce_slabs(part.view(d.S, -1)).view(d.D1, d.C + 1)                       # ... summed in subject order
+            grads["sb_b"] = ops.copy3d(torch.empty(d.D1, dtype=torch.float32, device=dev), dT1[:, d.C])
             dT1 = dT1[:, : d.C]
-            grads["sb_w"] = (dT1 @ Wd.t()).unsqueeze(-1)
-            dWd = (P["sb_w"][..., 0].t() @ dT1).contiguous()
+            grads["sb_w"] = ops.param_gemm(dT1, Wd.t()).unsqueeze(-1)
+            dWd = ops.param_gemm(P["sb_w"][..., 0].t(), dT1)
             grads["z"] = ops.sa_weights_backward(dWd, ctx.W_sa, ctx.mask, P["cosT"], P["sinT"], P["z"].shape[1],
                                                  bwd_table=P.get("sa_tab_b"))
             flush(["subj_w", "sb_w", "sb_b", "z"])
@@ -739,13 +739,7 @@ class ClipCtx:
     Zt: torch.Tensor
     row_elems: int
     dtemp: torch.Tensor
-    g_scale: float = 1.0          # power of two folded into G / rscale (fp16 only), divided out of the embedding gradient
-
-
-# dL/dlogits * exp(temp) / (|Y||Z|) is ~1e-5 at the training shapes: inside fp16's subnormal range.  The coefficient
-# matrix G (an MFMA operand, so it has to be 16-bit) is stored multiplied by this power of two and the factor is taken
-# out again in the fp32 epilogue of the dZ GEMM — exact, invisible to the caller.
-G_PRESCALE = {torch.float16: 4096.0}
+    cscale: Optional[torch.Tensor] = None     # per-column factor taken out of G (see sda_clip_grad): the dZ GEMM's acc_scale
 
 
 def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: int, Bn: int, T: int, col0: int = 0,
@@ -755,8 +749,11 @@ def clip_forward(Yt: torch.Tensor, Zt: torch.Tensor, temp: torch.Tensor, *, Bm: 
     brain rows.  Returns (loss_local_share, logits, ranks_count, ctx).  With `dist_group`, row statistics
     and the diagonal are merged across ranks so that the negatives span the global batch."""
     st = clip_block_stats(Yt, Zt, temp, Bm=Bm, Bn=Bn, T=T, col0=col0, ysq=ysq)
-    from .distributed import merge_row_softmax_stats
-    row_lse, diag = merge_row_softmax_stats(st.row_max, st.row_sum, dist_group, diag=st.diag)   # diag: zero where not owned
+    if dist_group is None:                       # one process: the block IS the whole matrix, its row lse came with the logits
+        row_lse, diag = st.row_lse, st.diag
+    else:
+        from .distributed import merge_row_softmax_stats
+        row_lse, diag = merge_row_softmax_stats(st.row_max, st.row_sum, dist_group, diag=st.diag)   # diag: zero where not owned
     return clip_block_finish(st, row_lse, diag, reduction=reduction, B_global=B_global)
 
 
@@ -777,6 +774,7 @@ class ClipBlockStats:
     row_sum: torch.Tensor
     col_lse: torch.Tensor
     diag: torch.Tensor
+    row_lse: torch.Tensor          # lse of each row over this block's columns only
 
 
 def clip_block_stats(Yt, Zt, temp, *, Bm: int, Bn: int, T: int, col0: int = 0, ysq=None) -> ClipBlockStats:
@@ -790,8 +788,8 @@ def clip_block_stats(Yt, Zt, temp, *, Bm: int, Bn: int, T: int, col0: int = 0, y
     if zsq is None:
         zsq = ops.rows_sumsq(Zt, Bn, row_elems, row_elems)
     S = ops.matmul_nt_splitk(Yt, Zt, Bm, Bn, row_elems, row_elems)
-    logits, row_max, row_sum, col_lse, diag = ops.clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0)
-    return ClipBlockStats(Yt, Zt, temp, Bm, Bn, col0, row_elems, ysq, zsq, logits, row_max, row_sum, col_lse, diag)
+    logits, row_max, row_sum, col_lse, diag, row_lse = ops.clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0)
+    return ClipBlockStats(Yt, Zt, temp, Bm, Bn, col0, row_elems, ysq, zsq, logits, row_max, row_sum, col_lse, diag, row_lse)
 
 
 def clip_block_finish(st: ClipBlockStats, row_lse, diag, *, reduction: str = "mean", B_global: Optional[int] = None):
@@ -801,19 +799,16 @@ def clip_block_finish(st: ClipBlockStats, row_lse, diag, *, reduction: str = "me
     logits, col_lse, ysq, zsq = st.logits, st.col_lse, st.ysq, st.zsq
     Bg = B_global if B_global is not None else Bm
     inv_norm = 1.0 / (2.0 * Bg) if reduction == "mean" else 0.5
-    gs = G_PRESCALE.get(Yt.dtype, 1.0)
-    G, rscale, scalars = ops.clip_grad(logits, row_lse, col_lse, ysq, zsq, temp, inv_norm * gs, col0, Yt.dtype)
-    if gs != 1.0:
-        scalars = scalars * (1.0 / gs)
+    # G is an MFMA operand (16-bit in the 16-bit modes): it holds the O(1) part of dL/dlogits * exp(temp) / (|Y||Z|), the
+    # rest — 1e-8 at the 8-GPU shapes, far outside fp16 — comes back as a per-column fp32 factor in the dZ GEMM's epilogue
+    G, rscale, cscale, scalars = ops.clip_grad(logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, Yt.dtype)
     cnt = ops.clip_ranks(logits, diag, col0)
     ctx = ClipCtx(Bm=Bm, Bn=Bn, col0=col0, G=G, rscale=rscale, Yt=Yt, Zt=Zt, row_elems=row_elems, dtemp=scalars[1:2],
-                  g_scale=gs)
+                  cscale=cscale)
     return scalars[0:1], logits, cnt, ctx
 
 
 def clip_backward(ctx: ClipCtx, dZt: torch.Tensor, dloss: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dZ = dloss * (G^T Y - diag(r) Z)  (gradient of the loss share w.r.t. the local brain embeddings)."""
-    if ctx.g_scale != 1.0:
-        dloss = (dloss if dloss is not None else torch.ones(1, dtype=torch.float32, device=dZt.device)) * (1.0 / ctx.g_scale)
+    """dZ = dloss * (diag(c) G^T Y - diag(r) Z)  (gradient of the loss share w.r.t. the local brain embeddings)."""
     return ops.matmul_tn_typed(ctx.G, ctx.Yt, dZt, ctx.Zt, ctx.rscale, M_rows=ctx.Bm, N_valid=ctx.Bn,
-                               K_cols=ctx.row_elems, pitch=ctx.row_elems, out_scale=dloss)
+                               K_cols=ctx.row_elems, pitch=ctx.row_elems, out_scale=dloss, acc_scale=ctx.cscale)

@@ -34,12 +34,18 @@ class WgradArgs(C.Structure):
                 ("seg_start", vp),
                 ("nseg", i32), ("B", i32), ("T", i32), ("Cout_p", i32), ("Cin_p", i32), ("KS", i32), ("dil", i32),
                 ("dy_pitch", i64), ("x_pitch", i64), ("out_pitch", i64), ("row0", i64), ("sample_rows", i64),
-                ("rows_limit", i64), ("dy_zero_row", i64), ("co_valid", i32), ("dtype", i32)]
+                ("rows_limit", i64), ("dy_zero_row", i64), ("co_valid", i32), ("dtype", i32), ("acc_scale", vp)]
 
 
 class PackDesc(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("nW", i32), ("Cout", i32), ("Cin", i32), ("KS", i32), ("Cout_p", i32),
                 ("Cin_p", i32), ("mode", i32), ("glu_half", i32), ("glu_half_p", i32), ("is_vector", i32), ("glu_tile", i32), ("total", i64)]
+
+
+class PgemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
+                ("a_i", i64), ("a_k", i64), ("a_b", i64), ("b_k", i64), ("b_j", i64), ("b_b", i64),
+                ("c_i", i64), ("c_j", i64), ("c_b", i64), ("c_dtype", i32)]
 
 
 class AdamDesc(C.Structure):
@@ -69,7 +75,7 @@ SIGNATURES = {
     "sda_conv_gemm": (i32, [C.POINTER(ConvArgs), vp]),
     "sda_conv_n_t_tiles": (i32, [i32]),
     "sda_conv_stats_rows": (i32, [i32, i32, i32, i32, i32]),
-    "sda_bn_finalize": (i32, [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "sda_bn_finalize": (i32, [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "sda_reduce_stats": (i32, [vp, i32, vp, vp, i32, vp]),
     "sda_bn_gelu_backward_from_stats": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, f64, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_bn_gelu_forward": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
@@ -98,11 +104,15 @@ SIGNATURES = {
     "sda_sa_softmax_pack": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "sda_sa_softmax_backward": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, vp]),
     "sda_sa_weights_backward": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "sda_clip_logits_stats": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "sda_clip_grad": (i32, [vp, vp, vp, vp, vp, vp, f32, i32, vp, i64, vp, vp, vp, i32, i32, i32, vp]),
+    "sda_clip_logits_stats": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "sda_clip_grad": (i32, [vp, vp, vp, vp, vp, vp, f32, i32, vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]),
     "sda_collate_rows": (i32, [vp, vp, i64, i32, i32, f32, i32, vp]),
     "sda_collate_windows": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "sda_clip_ranks": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "sda_param_gemm": (i32, [C.POINTER(PgemmArgs), vp]),
+    "sda_zero_pad_rows": (i32, [vp, i32, i32, i32, i32, vp]),
+    "sda_scalar_mul": (i32, [vp, vp, vp, i32, vp]),
+    "sda_copy3d": (i32, [vp, i64, i64, i64, vp, i64, i64, i64, i32, i32, i32, vp]),
 }
 
 _lib = None

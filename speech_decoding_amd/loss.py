@@ -241,11 +241,10 @@ class _ClipFn(torch.autograd.Function):
                                  "loss_func._state.ring_depth or call backward earlier")
             # a buffer of its own per backward (two pending backwards must not share one): the GEMM rewrites every sample's
             # rows, pad rows included (exact zeros), so only the slack behind the last sample needs a fill
-            dZt = torch.empty((L.rows_alloc(B, T), c.Zt.shape[1]), dtype=ctx.dtype, device=c.Zt.device)
-            dZt[B * L.rows_tp(T):].zero_()
+            dZt = ops.new_rows_uninit(B, T, c.Zt.shape[1], ctx.dtype, c.Zt.device)
             E.clip_backward(c, dZt, scale.reshape(1).contiguous())     # dloss folded into the GEMM epilogue
             dZ = ops.rows_view(dZt, B, F, T)
-        dtemp = (c.dtemp * scale).reshape(1)
+        dtemp = ops.scalar_mul(c.dtemp, scale.reshape(1))
         return None, None, dZ, dtemp
 
 

@@ -227,6 +227,7 @@ class BrainEncoder(nn.Module):
             blk = getattr(self.conv_blocks, f"conv{k}")
             for j, bn in ((0, blk.batchnorm0), (1, blk.batchnorm1)):
                 P[f"b{k}.bn{j}rm"], P[f"b{k}.bn{j}rv"] = bn.running_mean, bn.running_var
+                P[f"b{k}.bn{j}nbt"] = bn.num_batches_tracked        # counted by the statistics kernel itself (training mode)
         return P
 
     @property
@@ -274,12 +275,7 @@ class BrainEncoder(nn.Module):
                 dist.broadcast(mask, src=0, group=group)
         params = self._ordered_params()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # (grad mode is off inside Function.forward)
-        Z = _EncoderFn.apply(self, X, subject_idxs, mask, need_grad, *params)
-        if self.training:
-            counters = [bn.num_batches_tracked for k in range(5) for bn in
-                        (getattr(self.conv_blocks, f"conv{k}").batchnorm0, getattr(self.conv_blocks, f"conv{k}").batchnorm1)]
-            torch._foreach_add_(counters, 1)
-        return Z
+        return _EncoderFn.apply(self, X, subject_idxs, mask, need_grad, *params)
 
 
 class Classifier(nn.Module):

@@ -85,11 +85,21 @@ def new_rows(B: int, T: int, Cp: int, dtype, device) -> torch.Tensor:
 def new_rows_uninit(B: int, T: int, Cp: int, dtype, device) -> torch.Tensor:
     """RL buffer whose VALID rows are left uninitialised (the producing kernel writes all of them); the pad rows in
     front of every sample and the slack behind the last one are zeroed (two small fills instead of a full memset)."""
-    Tp = L.rows_tp(T)
     buf = torch.empty((L.rows_alloc(B, T), Cp), dtype=dtype, device=device)
-    buf.as_strided((B, L.ROW_PAD, Cp), (Tp * Cp, Cp, 1), 0).zero_()
-    buf[B * Tp:].zero_()
+    return zero_pad_rows(buf, B, T)
+
+
+def zero_pad_rows(buf: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    """Zero the pad rows in front of every sample and the slack behind the last one of an RL buffer (one small launch)."""
+    L.check(L.load().sda_zero_pad_rows(_p(buf), B, T, buf.shape[1], dt_code(buf.dtype), _st()), "zero_pad_rows")
     return buf
+
+
+def scalar_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a * b[0] for small fp32 device tensors (a: n elements, b: one)."""
+    out = torch.empty_like(a)
+    L.check(L.load().sda_scalar_mul(_p(a), _p(b), _p(out), a.numel(), _st()), "scalar_mul")
+    return out
 
 
 def rows_view(buf: torch.Tensor, B: int, C: int, T: int) -> torch.Tensor:
@@ -254,6 +264,48 @@ def unpack_vector(g: torch.Tensor, Cc: int, glu_half=0, glu_half_p=0) -> torch.T
     return out
 
 
+def param_gemm(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, out_dtype=torch.float32) -> torch.Tensor:
+    """out[b] = A[b] @ B[b] for fp32 operands of ANY strides — (M, K) @ (K, N), or batched (b, M, K) @ (b, K, N) where a 2-d
+    operand is shared by every batch member (views, transposes, slices: nothing is copied or made contiguous).  `out` may be
+    a view too (fp32, or the compute dtype: the product is then rounded on the way out); by default a new fp32 tensor."""
+    _need_cuda(A, B, out)
+    if A.dtype != torch.float32 or B.dtype != torch.float32:
+        raise L.SdaError("param_gemm: operands must be fp32")
+    batch = A.shape[0] if A.dim() == 3 else (B.shape[0] if B.dim() == 3 else 1)
+    M, K = A.shape[-2], A.shape[-1]
+    N = B.shape[-1]
+    if B.shape[-2] != K or (A.dim() == 3 and B.dim() == 3 and A.shape[0] != B.shape[0]):
+        raise L.SdaError(f"param_gemm: shapes {tuple(A.shape)} x {tuple(B.shape)} do not multiply")
+    batched = A.dim() == 3 or B.dim() == 3
+    if out is None:
+        out = torch.empty(((batch, M, N) if batched else (M, N)), dtype=out_dtype, device=A.device)
+    if tuple(out.shape[-2:]) != (M, N) or (out.dim() == 3) != batched or (batched and out.shape[0] != batch):
+        raise L.SdaError(f"param_gemm: output shape {tuple(out.shape)} does not match ({batch}, {M}, {N})")
+    a = L.PgemmArgs()
+    a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    a.M, a.N, a.K, a.batch = M, N, K, batch
+    a.a_i, a.a_k, a.a_b = A.stride(-2), A.stride(-1), (A.stride(0) if A.dim() == 3 else 0)
+    a.b_k, a.b_j, a.b_b = B.stride(-2), B.stride(-1), (B.stride(0) if B.dim() == 3 else 0)
+    a.c_i, a.c_j, a.c_b = out.stride(-2), out.stride(-1), (out.stride(0) if out.dim() == 3 else 0)
+    a.c_dtype = dt_code(out.dtype)
+    L.check(L.load().sda_param_gemm(C.byref(a), _st()), "param_gemm")
+    return out
+
+
+def copy3d(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """dst[...] = src[...] for fp32 views of equal shape (up to 3 dims) and any strides — one small kernel instead of a
+    framework copy (column inserts, permuted packs of a parameter)."""
+    _need_cuda(dst, src)
+    if dst.shape != src.shape or dst.dim() > 3 or dst.dtype != torch.float32 or src.dtype != torch.float32:
+        raise L.SdaError("copy3d: fp32 views of equal shape with at most three dimensions")
+    pad = 3 - dst.dim()
+    n = [1] * pad + list(dst.shape)
+    d = [0] * pad + list(dst.stride())
+    s_ = [0] * pad + list(src.stride())
+    L.check(L.load().sda_copy3d(dst.data_ptr(), d[0], d[1], d[2], src.data_ptr(), s_[0], s_[1], s_[2], n[0], n[1], n[2], _st()), "copy3d")
+    return dst
+
+
 class KernelTimer:
     """Optional HIP-event timing of individual launches on the current stream (bench.py's roofline leg).
     Off by default: `ops.TIMER = KernelTimer()` turns it on, `ops.TIMER = None` off."""
@@ -358,16 +410,19 @@ def matmul_nt_splitk(xm: torch.Tensor, wm: torch.Tensor, M: int, N: int, K: int,
 
 
 def bn_finalize(partial, ntiles, count, gamma, beta, running_mean, running_var, Cp, training, eps=1e-5, momentum=0.1,
-                want_bwd_coef=False):
+                want_bwd_coef=False, batches_tracked=None):
     """Returns (mean, rstd, scale, shift[, bwd_coef]); bwd_coef = [4][Cp] (gamma, beta, mean, rstd), the table the
-    data-gradient conv reads in its BatchNorm-backward statistics mode."""
+    data-gradient conv reads in its BatchNorm-backward statistics mode.  batches_tracked: the module's int64
+    num_batches_tracked buffer, incremented by the same launch in training mode."""
+    if batches_tracked is not None and (batches_tracked.dtype != torch.int64 or not batches_tracked.is_cuda):
+        raise L.SdaError("bn_finalize: batches_tracked must be an int64 device tensor")
     dev = gamma.device
     buf = torch.empty((8 if want_bwd_coef else 4, Cp), dtype=torch.float32, device=dev)
     mean, rstd, scale, shift = buf[0], buf[1], buf[2], buf[3]
     coef = buf[4:] if want_bwd_coef else None
     L.check(L.load().sda_bn_finalize(_p(partial), ntiles, float(count), _p(gamma), _p(beta), eps, momentum,
                                      _p(running_mean), _p(running_var), _p(mean), _p(rstd), _p(scale), _p(shift),
-                                     _p(coef), gamma.numel(), Cp, int(training), _st()), "bn_finalize")
+                                     _p(coef), gamma.numel(), Cp, int(training), _p(batches_tracked), _st()), "bn_finalize")
     return (mean, rstd, scale, shift, coef) if want_bwd_coef else (mean, rstd, scale, shift)
 
 
@@ -489,7 +544,7 @@ def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1, alg_d
     a.nseg, a.B, a.T, a.Cout_p, a.Cin_p, a.KS, a.dil = nseg, B, T, dy.shape[1], x.shape[1], KS, dil
     a.dy_pitch, a.x_pitch, a.out_pitch = dy.shape[1], x.shape[1], 0
     a.row0, a.sample_rows, a.rows_limit, a.dy_zero_row = L.ROW_PAD, L.rows_tp(T), x.shape[0], 0
-    a.co_valid, a.dtype = 0, dt_code(x.dtype)
+    a.co_valid, a.dtype, a.acc_scale = 0, dt_code(x.dtype), None
     if nseg > 1 and seg_start is None:
         raise L.SdaError("wgrad_gemm: nseg > 1 needs seg_start")
     if TIMER is not None and "wgrad_gemm" in TIMER.families:   # events go on the CURRENT stream (the side stream in backward)
@@ -515,9 +570,10 @@ def reduce_slabs(slabs: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def matmul_tn_typed(G, Ym, out, sub, rscale, *, M_rows, N_valid, K_cols, pitch, out_scale=None):
-    """out[j][k] = out_scale * (sum_i G[i][j] * Ym[i][k] - rscale[j] * sub[j][k])   (typed rows with `pitch`)."""
+def matmul_tn_typed(G, Ym, out, sub, rscale, *, M_rows, N_valid, K_cols, pitch, out_scale=None, acc_scale=None):
+    """out[j][k] = out_scale * (acc_scale[j] * sum_i G[i][j] * Ym[i][k] - rscale[j] * sub[j][k])   (typed rows with `pitch`)."""
     a = L.WgradArgs()
+    a.acc_scale = _p(acc_scale)
     a.dy, a.x, a.g, a.out_e, a.sub, a.rscale, a.out_scale = _p(G), _p(Ym), None, _p(out), _p(sub), _p(rscale), _p(out_scale)
     a.perm, a.seg_start = None, None
     a.nseg, a.B, a.T, a.Cout_p, a.Cin_p, a.KS, a.dil = 1, 1, M_rows, G.shape[1], K_cols, 1, 0
@@ -587,23 +643,26 @@ def clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0):
     row_max = torch.empty(Bm, dtype=torch.float32, device=dev)
     row_sum = torch.empty(Bm, dtype=torch.float32, device=dev)
     col_lse = torch.empty(Bn, dtype=torch.float32, device=dev)
-    diag = torch.zeros(Bm, dtype=torch.float32, device=dev)
+    diag = torch.empty(Bm, dtype=torch.float32, device=dev)           # (every row is written: zero where the positive lives elsewhere)
+    row_lse = torch.empty(Bm, dtype=torch.float32, device=dev)        # lse over THIS block of columns
     L.check(L.load().sda_clip_logits_stats(_p(S), S.shape[1], _p(ysq), _p(zsq), _p(temp), _p(logits), _p(row_max), _p(row_sum),
-                                           _p(col_lse), _p(diag), Bm, Bn, col0, _st()), "clip_logits_stats")
-    return logits, row_max, row_sum, col_lse, diag
+                                           _p(col_lse), _p(diag), _p(row_lse), Bm, Bn, col0, _st()), "clip_logits_stats")
+    return logits, row_max, row_sum, col_lse, diag, row_lse
 
 
 def clip_grad(logits, row_lse, col_lse, ysq, zsq, temp, inv_norm, col0, dtype):
     Bm, Bn = logits.shape
     dev = logits.device
-    G = torch.zeros((Bm + 1, L.pad_channels(Bn)), dtype=dtype, device=dev)      # + one zero row (wgrad_gemm's t >= T stand-in)
+    G = torch.empty((Bm + 1, L.pad_channels(Bn)), dtype=dtype, device=dev)      # + one zero row (wgrad_gemm's t >= T stand-in):
+                                                                                 # it and the padding columns are written by the kernel
     rscale = torch.empty(Bn, dtype=torch.float32, device=dev)
+    cscale = torch.empty(Bn, dtype=torch.float32, device=dev)
     colpart = torch.empty(2 * Bn, dtype=torch.float32, device=dev)
     scalars = torch.empty(2, dtype=torch.float32, device=dev)
     L.check(L.load().sda_clip_grad(_p(logits), _p(row_lse), _p(col_lse), _p(ysq), _p(zsq), _p(temp), float(inv_norm), col0,
-                                   _p(G), G.shape[1], _p(rscale), _p(colpart), _p(scalars), Bm, Bn, dt_code(dtype), _st()),
+                                   _p(G), G.shape[1], _p(rscale), _p(cscale), _p(colpart), _p(scalars), Bm, Bn, dt_code(dtype), _st()),
             "clip_grad")
-    return G, rscale, scalars
+    return G, rscale, cscale, scalars
 
 
 def clip_ranks(logits, diag, col0):

@@ -484,3 +484,65 @@ def test_fused_adam_matches_torch_adam(ops):
     for a, b in zip(pa, pb):
         ra, rb = (torch.view_as_real(a), torch.view_as_real(b)) if a.is_complex() else (a, b)
         assert float((ra - rb).abs().max()) < 2e-7 + 1e-6 * float(ra.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# parameter-space products (csrc/param_gemm.hip): the composed SubjectBlock's small fp32 matrix products on strided views
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["plain", "a_transposed", "b_transposed", "batched_a", "batched_b", "batched_both_sliced",
+                                  "tiny", "wide_tiles", "typed_out_into_view"])
+def test_param_gemm_on_strided_views_against_fp64(ops, case):
+    g = torch.Generator().manual_seed(len(case))
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g).to(DEV)
+
+    out = None
+    if case == "plain":
+        A, B = rnd(270, 270), rnd(270, 208)
+    elif case == "a_transposed":                     # K runs along A's slow index
+        A, B = rnd(270, 270).t(), rnd(270, 208)
+    elif case == "b_transposed":
+        A, B = rnd(270, 208), rnd(270, 208).t()
+    elif case == "batched_a":                        # 3-d A, shared 2-d B (the composition W_subj[s] . T1aug)
+        A, B = rnd(27, 270, 270), rnd(270, 209)
+    elif case == "batched_b":                        # shared 2-d A, 3-d B
+        A, B = rnd(270, 960), rnd(5, 960, 256)[:, :, :209]
+    elif case == "batched_both_sliced":              # sliced, transposed batch operands (chain rule: W_subj[s]^T . G[s])
+        A, B = rnd(7, 300, 270)[:, :270].transpose(1, 2), rnd(7, 320, 256)[:, :270, :209]
+    elif case == "tiny":
+        A, B = rnd(3, 5), rnd(5, 2)
+    elif case == "wide_tiles":                       # enough tiles for the 128 x 128 variant
+        A, B = rnd(12, 700, 77), rnd(12, 77, 650)
+    else:                                            # bf16 result written into a slice of a padded, zero-initialised buffer
+        A, B = rnd(4, 270, 270), rnd(270, 209)
+        buf = torch.zeros((4, 1, 320, 256), dtype=torch.bfloat16, device=DEV)
+        out = buf[:, 0, :270, :209]
+    got = ops.param_gemm(A, B, out=out)
+    ref = torch.matmul(A.double().cpu(), B.double().cpu())
+    scale = float(ref.abs().max())
+    if out is None:
+        assert got.dtype == torch.float32 and got.is_contiguous()
+        assert float((got.double().cpu() - ref).abs().max()) <= 2e-6 * scale * math.sqrt(A.shape[-1])
+    else:
+        assert got.data_ptr() == out.data_ptr()
+        assert float((got.double().cpu() - ref).abs().max()) <= 2 ** -8 * scale
+        mask = torch.ones_like(buf, dtype=torch.bool)
+        mask[:, 0, :270, :209] = False
+        assert float(buf[mask].float().abs().max()) == 0.0          # nothing outside the view is touched
+    again = ops.param_gemm(A, B, out=None if out is None else torch.zeros_like(buf)[:, 0, :270, :209])
+    assert torch.equal(again.float(), got.float())                 # fixed summation order: bitwise reproducible
+
+
+def test_copy3d_strided(ops):
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(320, 270, 3, generator=g).to(DEV)                              # a conv weight [o][d][tap]
+    dst = torch.zeros((270, 3, 384), dtype=torch.float32, device=DEV)
+    ops.copy3d(dst[:, :, :320], w.permute(1, 2, 0))
+    assert torch.equal(dst[:, :, :320], w.permute(1, 2, 0)) and float(dst[:, :, 320:].abs().max()) == 0.0
+    col = torch.randn(270, generator=g).to(DEV)
+    T1 = torch.zeros((270, 209), device=DEV)
+    ops.copy3d(T1[:, 208:], col[:, None])
+    assert torch.equal(T1[:, 208], col) and float(T1[:, :208].abs().max()) == 0.0
+    out = ops.copy3d(torch.empty(270, device=DEV), T1[:, 208])
+    assert torch.equal(out, col) and out.is_contiguous()

@@ -80,7 +80,12 @@ def test_global_negative_loss_block_at_full_size(name, world, Bn, T, dtype, dist
     cnt = torch.zeros(Bg, dtype=torch.int32, device=DEV)
     logits = torch.empty((Bg, Bg), dtype=torch.float32, device=DEV)
     dZ = {}
-    one = torch.ones(1, dtype=torch.float32, device=DEV)
+    # the incoming gradient: 1, or in fp16 the static loss scale of a run of this size (amp.fp16_scale_for: the embedding gradient is
+    # ~2e-8 at 4096 x 1000 samples, below fp16's smallest subnormal — as in any fp16 training the backward pass runs scaled by a
+    # power of two, exactly removed again below)
+    from speech_decoding_amd.amp import fp16_scale_for
+    gscale = fp16_scale_for(Bg, T) if dtype == "fp16" else 1.0
+    one = torch.full((1,), gscale, dtype=torch.float32, device=DEV)
     for r in range(world):
         share, lg, c, cctx = E.clip_block_finish(stats[r], row_lse, diag, B_global=Bg)
         loss += share
@@ -91,7 +96,7 @@ def test_global_negative_loss_block_at_full_size(name, world, Bn, T, dtype, dist
             dZt = torch.empty((L.rows_alloc(Bn, T), Yt.shape[1]), dtype=tdt, device=DEV)
             dZt[Bn * L.rows_tp(T):].zero_()
             E.clip_backward(cctx, dZt, one)
-            dZ[r] = ops.rows_view(dZt, Bn, F, T).float().cpu().reshape(Bn, N)
+            dZ[r] = ops.rows_view(dZt, Bn, F, T).float().cpu().reshape(Bn, N) / gscale
             assert float(dZt[: L.ROW_PAD].float().abs().max()) == 0.0          # pad rows come out as exact zeros
     torch.cuda.synchronize()
 

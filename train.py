@@ -107,7 +107,9 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
         wandb.run.name = args.wandb.run_name + "_" + str(args.split_mode)
 
     from speech_decoding_amd.amp import LossScaler
-    scaler = LossScaler.for_dtype(brain_encoder.compute_dtype, float(args.get("fp16_loss_scale", 1024.0)))   # no-op unless fp16
+    seq_T = int(args.preprocs["seq_len_sec"] * args.preprocs["brain_resample_rate"])
+    scaler = LossScaler.for_dtype(brain_encoder.compute_dtype, float(args.get("fp16_loss_scale", 1024.0)),
+                                  global_batch=int(args.batch_size), T=seq_T)                      # no-op unless fp16
 
     fp16 = scaler.scale_value != 1.0
 
