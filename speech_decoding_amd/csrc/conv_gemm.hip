@@ -29,9 +29,16 @@ template <int TILE_CO, int CH = 4> struct EpiGeom {
 };
 
 template <int TILE_CO, int KS, int NT> constexpr int conv_stage_bytes() { return NT * XS_BYTES + KS * TILE_CO * ROW_B; }
-template <int NT, int KS> constexpr int conv_stages() { return (NT == 2 && KS == 3) ? 3 : 2; }
-template <int TILE_CO, int KS, int NT> constexpr int conv_lds_bytes() {
-  constexpr int main_b = conv_stages<NT, KS>() * conv_stage_bytes<TILE_CO, KS, NT>();
+// LDS stages of the K loop: 3 for the paired kernel-3 tiles, a RING of 4 (3 for 160-channel tiles: 60 KB, two workgroups per
+// CU) for single-tile kernel-size-1 launches — a K-step there is 16 MFMAs per wave, far less than one LDS-DMA round trip, so
+// two / three slabs stay in flight behind counted waits — in split-K matrix mode (SV = false), 2 otherwise.
+// (measured, config-2 shapes alone: the similarity matmul 203 -> 114 us at 256 x 256 samples, 710 -> 631 us at 2048 x 256;
+// the row-layout 1x1 convs, whose time is their epilogue's, gained nothing and lose co-residency: they keep two stages)
+template <int TILE_CO, int NT, int KS, bool SV> constexpr int conv_stages() {
+  return (NT == 2 && KS == 3) ? 3 : ((NT == 1 && KS == 1 && !SV) ? (TILE_CO > 128 ? 3 : 4) : 2);
+}
+template <int TILE_CO, int KS, int NT, bool SV = true> constexpr int conv_lds_bytes() {
+  constexpr int main_b = conv_stages<TILE_CO, NT, KS, SV>() * conv_stage_bytes<TILE_CO, KS, NT>();
   constexpr int epi_b = NT * (EpiGeom<TILE_CO, 8>::EP_BYTES + EpiGeom<TILE_CO, 8>::RED_BYTES);   // CH = 8 is the larger
   return main_b > epi_b ? main_b : epi_b;
 }
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
     }
   };
 
-  constexpr int NS = conv_stages<NT, KS>();
+  constexpr int NS = conv_stages<TILE_CO, NT, KS, SV>();
   auto compute_tap = [&](const unsigned char* xs, const unsigned char* ws, int tap, auto&& between) {
     uint4 af[4], bf[NREP];
     const int xrow = wave_t * 64 + lr + tap * dil;
@@ -211,7 +218,63 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
     }
   };
 
-  if constexpr (NS == 2) {
+  if constexpr (KS == 1 && NT == 1 && !SV) {
+    // Ring of NS stages, D = NS - 1 slabs of LDS-DMA in flight.  Every wave issues EXACTLY PPW pieces per slab (2 input + 2 or 3
+    // weight pieces; indices past the end are clamped, duplicates rewrite identical bytes), so a counted s_waitcnt retires slab
+    // s while its successors stay in flight across the raw s_barrier.  Slab s + D goes into the buffer slab s - 1 was read
+    // from: every wave has passed this iteration's barrier, i.e. has consumed it.
+    constexpr int D = NS - 1;
+    constexpr int NXW = 2, NWW = (TP + NW - 1) / NW, PPW = NXW + NWW;
+    static_assert(4 * NXW * 16 == TILE_T, "two 16-row input pieces per wave cover the 128-row tile");
+    auto issue_fixed = [&](int s, int buf, int j) {       // j-th of this wave's PPW pieces of slab s
+      if (j < NXW) {
+        const int pc = (wid & 3) + 4 * j;
+        dma_x(s, pc, buf * STAGE + tsel * XS_BYTES + pc * 1024);
+      } else {
+        int q = wid + NW * (j - NXW);
+        q = q < TP ? q : TP - 1;
+        dma_w(s, 0, q, buf * STAGE + NT * XS_BYTES + q * 1024);
+      }
+    };
+    auto wait_keep = [&](int slabs_in_flight) {           // all but this wave's youngest slabs_in_flight * PPW operations
+      switch (slabs_in_flight * PPW) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    };
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+      if (s_begin + p < s_end) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue_fixed(s_begin + p, p, j);
+      }
+    }
+    int cur = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+      const int younger = s_end - 1 - s;
+      wait_keep(younger < D - 1 ? younger : D - 1);
+      __builtin_amdgcn_s_barrier();
+      const bool more = s + D < s_end;
+      const int nxt = cur == 0 ? NS - 1 : cur - 1;        // (cur + D) % NS: the buffer of slab s - 1
+      const unsigned char* xs = smem + cur * STAGE + tsel * XS_BYTES;
+      const unsigned char* ws = smem + cur * STAGE + NT * XS_BYTES;
+      constexpr int PER = (PPW + 3) / 4;                  // pieces after each of the four MFMA rows
+      compute_slab_spread(xs, ws, [&](int tap, int m) {
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < PER; ++i) {
+            if (m * PER + i < PPW) issue_fixed(s + D, nxt, m * PER + i);
+          }
+        }
+      });
+      cur = cur == NS - 1 ? 0 : cur + 1;
+    }
+  } else if constexpr (NS == 2) {
     if (s_begin < s_end) {
       stage_x(s_begin, 0);
 #pragma unroll
@@ -422,7 +485,10 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
           if (a.flags & SDA_EPI_GELU) {
             if (ypre) Vec16<E>::store(ypre + off, v);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) v[j] = gelu_f<E>(v[j]);
+            for (int j = 0; j < CH; j += 2) {          // on pairs: the 16-bit form's arithmetic is packed (two elements per issue slot)
+              const f32x2 gp = gelu_pair<E>(f32x2{v[j], v[j + 1]});
+              v[j] = gp.x; v[j + 1] = gp.y;
+            }
           }
           if constexpr (!BN) {
             if (a.flags & SDA_EPI_GLU_BWD) {
@@ -491,7 +557,7 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
 
 template <typename E, int TILE_CO, int KS, int NT, bool BN = false, bool SV = true>
 static int launch_conv(const sda_conv_args& a, hipStream_t st) {
-  constexpr int lds = conv_lds_bytes<TILE_CO, KS, NT>();
+  constexpr int lds = conv_lds_bytes<TILE_CO, KS, NT, SV>();
   static bool attr_done = false;
   auto kern = conv_gemm_kernel<E, TILE_CO, KS, NT, BN, SV>;
   if (!attr_done) {

@@ -26,10 +26,13 @@ def main():
         y, yp = ops.new_rows(B, T, cout, dtype, dev), ops.new_rows(B, T, cout, dtype, dev)
         bias = torch.zeros(cout, device=dev)
         idx = torch.randint(0, S, (B,), dtype=torch.int32, device=dev) if widx else None
-        us = timeit(lambda: ops.conv_gemm(x, wp, y, B=B, T=T, KS=1, dil=0, bias=bias, gelu=gelu, y_pre=yp if pre else None, widx=idx))
         fl = 2.0 * B * T * cin * cout
         mb = B * T * (cin + cout * (2 if pre else 1)) * 2 / 1e6
-        print(f"{name:28s} {cin:4d}->{cout:4d}  {us:7.1f} us  {fl / us / 1e6:6.1f} TF  {mb:5.0f} MB  {mb / us:5.2f} TB/s", flush=True)
+        for tag, flags in (("single", 0), ("paired", L.CONV_PAIR_TILES)):
+            if widx and flags:
+                continue
+            us = timeit(lambda: ops.conv_gemm(x, wp, y, B=B, T=T, KS=1, dil=0, bias=bias, gelu=gelu, y_pre=yp if pre else None, widx=idx, flags=flags))
+            print(f"{name:28s} {cin:4d}->{cout:4d} {tag:7s} {us:7.1f} us  {fl / us / 1e6:6.1f} TF  {mb:5.0f} MB  {mb / us:5.2f} TB/s", flush=True)
 
 if __name__ == "__main__":
     main()
