@@ -284,6 +284,14 @@ int sda_clip_logits_stats(const float* S, long s_pitch, const float* ysq, const 
 int sda_clip_grad(const float* logits, const float* row_lse, const float* col_lse, const float* ysq,
                   const float* zsq, const float* temp, float inv_norm, int col0, void* G, long g_pitch,
                   float* rscale, float* cscale, float* colpart, float* scalars, int Bm, int Bn, int dtype, void* stream);
+/* The embedding gradient of the loss on one GPU as a streaming kernel (loss_gemm.hip):
+ *     out[j][k] = out_scale[0] * (cscale[j] * sum_{i < Bm} G[i][j] * Y[i][k] - rscale[j] * Z[j][k]),   j < Bn, k < row_elems
+ * G [Bm][g_pitch], Y [Bm][row_elems], Z and out [Bn][row_elems] of `dtype` (16-bit types only), cscale / rscale fp32 [Bn]
+ * (cscale may be NULL = 1), out_scale a device scalar or NULL.  Same result as sda_wgrad_gemm's typed-output mode, which
+ * serves what this one does not: sda_clip_dz_supported() says whether (Bm <= 256, row_elems % 64 == 0, bf16 / fp16) holds. */
+int sda_clip_dz_supported(int Bm, int Bn, long row_elems, int dtype);
+int sda_clip_dz(const void* G, long g_pitch, const void* Y, const void* Z, void* out, const float* cscale, const float* rscale,
+                const float* out_scale, int Bm, int Bn, long row_elems, int dtype, void* stream);
 /* cnt[i] = #{local j : logits[i][j] beats diag[i]} (ties: lower global index wins) — Classifier ranks */
 int sda_clip_ranks(const float* logits, const float* diag, int32_t* cnt, int Bm, int Bn, int col0, void* stream);
 int sda_device_count(void);

@@ -1,0 +1,194 @@
+// loss_gemm — the embedding gradient of the CLIP loss on one GPU, as a STREAMING kernel.
+//
+// Reference op: autograd of `logits = x @ y.T` (loss.py:68) with respect to the brain embeddings y = Z:
+//     dZ[j][k] = dloss * ( cscale[j] * sum_{i < Bm} G[i][j] * Y[i][k]  -  rscale[j] * Z[j][k] ),     j < Bn, k < row_elems
+// (G, cscale, rscale from sda_clip_grad).  The contraction runs over the BATCH only (Bm <= 256 speech rows), the other
+// extent is a whole embedding (F x T = 368 640 ... 1 024 000 elements): 50 GFLOP against 591 MB of unavoidable traffic
+// at config 2 (read Y, read Z, write dZ, 197 MB each) — HBM-bound by a factor of four at any sensible MFMA rate.  The
+// general kernel (wgrad_gemm, typed output) tiles this as 6 016 independent 128 x 128 problems of four K-chunks each,
+// every one with its own prologue, barriers and fp32 staging epilogue: 250 us.  Here instead:
+//   * the coefficient matrix never moves: every wave keeps G's fragments for its 64 columns j in REGISTERS for the whole
+//     kernel (<= 8 K-steps x 4 fragments = 128 VGPRs), loaded once;
+//   * persistent workgroups (two per CU) walk 64-element column tiles of the embeddings: the (256 x 128 B) slice of Y
+//     arrives by LDS-DMA, double-buffered one tile ahead, is read as the TRANSPOSED MFMA operand (ds_read_b64_tr_b16:
+//     the contraction index is the image's row), D[k][j] = sum_i Y[i][k] G[i][j] lands with 4 consecutive k per lane;
+//   * the epilogue is per wave (no workgroup barrier): 16 x 32 accumulator blocks pass through a 2 KB private LDS patch
+//     to become 16-byte row segments, Z is read and dZ written with 16 bytes per lane, each byte exactly once.
+// Y, Z and dZ are each touched once; bound: HBM (591 MB per launch at config 2 -> ~100 us at 6 TB/s).
+#include "sd_common.h"
+#include "tr_operand.h"
+
+namespace sda {
+
+namespace {
+
+constexpr int DZ_KT = 64;                              // embedding elements (columns) per tile: 128 bytes per row
+constexpr int DZ_ROWS = 256;                           // contraction rows staged per tile (Bm <= 256)
+constexpr int DZ_YB = DZ_ROWS * DZ_KT * 2;             // 32 KB per Y image
+constexpr int DZ_STG = 16 * 32 * 4;                    // per-wave epilogue patch: 16 rows j x 32 columns k, fp32
+constexpr int DZ_LDS = 2 * DZ_YB + 4 * DZ_STG;         // 73 728 B: two workgroups per CU
+
+template <typename E>
+__global__ __launch_bounds__(256, 2) void clip_dz_kernel(const E* __restrict__ G, long g_pitch, const E* __restrict__ Y,
+                                                         const E* __restrict__ Z, E* __restrict__ out,
+                                                         const float* __restrict__ cscale, const float* __restrict__ rscale,
+                                                         const float* __restrict__ out_scale, int Bm, int Bn, long row_elems,
+                                                         int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int jwave = blockIdx.y * 256 + wid * 64;       // this wave's 64 brain columns j
+  const int nks = (Bm + 31) >> 5;                      // K-steps of 32 speech rows
+
+  // G fragments (the MFMA's B operand: column j = lr, contraction i in the order the transposed reads of Y deliver it:
+  // lane group lq holds i = 32 ks + {4 lq .. 4 lq + 3, 16 + 4 lq .. 16 + 4 lq + 3}); rows / columns past the matrix are zero
+  uint4 gf[8][4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      const int j = jwave + nf * 16 + lr;
+      if (ks < nks && j < Bn) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int i = ks * 32 + (e < 4 ? 4 * lq + e : 16 + 4 * lq + (e - 4));
+          const uint32_t v = i < Bm ? (uint32_t)*reinterpret_cast<const uint16_t*>(G + (size_t)i * g_pitch + j) : 0u;
+          w[e >> 1] |= v << (16 * (e & 1));
+        }
+      }
+      gf[ks][nf] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+
+  // LDS-DMA of one Y tile: 32 pieces of 8 rows x 128 B, lane-linear in LDS, chunk swizzle on the source (tr_operand.h)
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const int prow = lane >> 3, pchunk = lane & 7;
+  auto stage = [&](int tile, int buf) {
+    const long k0 = (long)tile * DZ_KT;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int piece = wid * 8 + p;
+      const int row = piece * 8 + prow;
+      const int src_row = row < Bm ? row : Bm - 1;     // (rows past the batch meet zero coefficients: any finite data will do)
+      const int c = pchunk ^ chunk_xor<E, 128>(row);
+      lds_dma16(Y + (size_t)src_row * row_elems + k0 + c * 8, lds_base + buf * DZ_YB + piece * 1024);
+    }
+  };
+
+  float* stg = reinterpret_cast<float*>(smem + 2 * DZ_YB + wid * DZ_STG);
+  const float os = out_scale ? out_scale[0] : 1.f;
+  int tile = blockIdx.x, buf = 0;
+  if (tile < ntiles) stage(tile, 0);
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tile have landed (and its stores have left)
+    __builtin_amdgcn_s_barrier();                       // ... everybody's; the other image is no longer being read
+    const long k0 = (long)tile * DZ_KT;
+    // this lane's eight 16-byte pieces of Z for the tile's epilogue passes, requested now: they arrive behind the MFMAs (a
+    // load issued inside its pass is a full memory round trip per pass, eight in a row per tile)
+    const int jr = lane >> 2, c8 = lane & 3;           // row of an epilogue patch, which 8 of its 32 columns
+    uint4 zraw[2][4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int j = jwave + n * 16 + jr;
+        zraw[half][n] = make_uint4(0u, 0u, 0u, 0u);
+        if (j < Bn) zraw[half][n] = Vec16<E>::load_raw(Z + (size_t)j * row_elems + k0 + half * 32 + c8 * 8);
+      }
+    if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, buf ^ 1);
+    const unsigned char* img = smem + buf * DZ_YB;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {             // 32 columns k at a time: 8 accumulator fragments
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks < nks) {
+          const uint4 a0 = tr_operand_bf16<128>(img, ks * 32, half * 32, lane);
+          const uint4 a1 = tr_operand_bf16<128>(img, ks * 32, half * 32 + 16, lane);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            acc[0][n] = mma16<E>(a0, gf[ks][n], acc[0][n]);
+            acc[1][n] = mma16<E>(a1, gf[ks][n], acc[1][n]);
+          }
+        }
+      }
+      // accumulator layout: column j = lr, rows k = 16 m + 4 lq + r.  Per 16-column block nf: patch[j][k] fp32 (XOR-swizzled
+      // 16-byte chunks), then lane -> (row j = lane >> 2, 8 consecutive k): 16-byte accesses to Z and dZ
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int ch = (m * 4 + lq) ^ (lr & 7);      // 16-byte chunk (4 floats) of row lr, swizzled
+          *reinterpret_cast<f32x4*>(stg + lr * 32 + ch * 4) = acc[m][n];
+        }
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + jr * 32 + (((2 * c8) ^ (jr & 7)) * 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + jr * 32 + (((2 * c8 + 1) ^ (jr & 7)) * 4));
+        const int j = jwave + n * 16 + jr;
+        if (j < Bn) {
+          const size_t off = (size_t)j * row_elems + k0 + half * 32 + c8 * 8;
+          const float cs = cscale ? cscale[j] : 1.f, rs = rscale[j];
+          float z[8], v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          Vec16<E>::unpack(zraw[half][n], z);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = os * (cs * v[e] - rs * z[e]);
+          Vec16<E>::store(out + off, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename E>
+int launch_dz(const void* G, long g_pitch, const void* Y, const void* Z, void* out, const float* cscale, const float* rscale,
+              const float* out_scale, int Bm, int Bn, long row_elems, hipStream_t st) {
+  static bool attr_done = false;
+  auto kern = clip_dz_kernel<E>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DZ_LDS) != hipSuccess) {
+      set_error("clip_dz: cannot reserve %d bytes of LDS", DZ_LDS);
+      return -3;
+    }
+    attr_done = true;
+  }
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const int ntiles = (int)(row_elems / DZ_KT);
+  const int jblocks = (Bn + 255) / 256;
+  int gx = 2 * cus / jblocks;                          // two workgroups per CU in all
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = ntiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)jblocks), dim3(256), DZ_LDS, st, (const E*)G, g_pitch, (const E*)Y, (const E*)Z,
+                     (E*)out, cscale, rscale, out_scale, Bm, Bn, row_elems, ntiles);
+  return check_launch("clip_dz");
+}
+
+}  // namespace
+}  // namespace sda
+
+using namespace sda;
+
+extern "C" int sda_clip_dz_supported(int Bm, int Bn, long row_elems, int dtype) {
+  return (dtype == SDA_BF16 || dtype == SDA_F16) && Bm >= 1 && Bm <= DZ_ROWS && Bn >= 1 && row_elems >= DZ_KT && row_elems % DZ_KT == 0 &&
+         row_elems / DZ_KT < 0x7fffffffL;
+}
+
+extern "C" int sda_clip_dz(const void* G, long g_pitch, const void* Y, const void* Z, void* out, const float* cscale,
+                           const float* rscale, const float* out_scale, int Bm, int Bn, long row_elems, int dtype, void* stream) {
+  if (!G || !Y || !Z || !out || !rscale || g_pitch < Bn) { set_error("clip_dz: bad arguments"); return -1; }
+  if (!sda_clip_dz_supported(Bm, Bn, row_elems, dtype)) {
+    set_error("clip_dz: needs a 16-bit dtype, Bm <= %d and row_elems %% %d == 0 (use sda_wgrad_gemm's typed output otherwise)", DZ_ROWS, DZ_KT);
+    return -1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SDA_BF16) return launch_dz<uint16_t>(G, g_pitch, Y, Z, out, cscale, rscale, out_scale, Bm, Bn, row_elems, st);
+  return launch_dz<half_t>(G, g_pitch, Y, Z, out, cscale, rscale, out_scale, Bm, Bn, row_elems, st);
+}

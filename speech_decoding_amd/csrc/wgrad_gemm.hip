@@ -13,6 +13,7 @@
 // image at row offsets tap*dil.  Segments make the K split explicit: per-subject weight gradients use one
 // segment per subject (final result, no reduction), shared weights use ~CU-count segments + reduce_slabs.
 #include "sd_common.h"
+#include "tr_operand.h"
 
 #include <type_traits>
 #include <utility>
@@ -50,63 +51,6 @@ __device__ inline void wait_vmcnt_dyn(int n) {
 
 typedef __attribute__((address_space(1))) const void gmem_cv;
 typedef __attribute__((address_space(3))) void lds_v;
-
-// LDS images are plain row-major copies (row = time step, RB bytes per row, no padding) filled by 1 KB
-// LDS-DMA pieces; bank conflicts of the TRANSPOSED operand reads are removed by XOR-ing the 16-byte chunk
-// index with a function of the row (applied to the DMA source address and to the read address alike):
-//   bf16 (ds_read_b64_tr_b16, a 32-lane half reads 8 consecutive rows x 32 B):  32-byte groups
-//       RB = 128: group ^= (row >> 1) & 3     RB = 256: group ^= row & 7     RB = 320: group ^= (row >> 2) & 1
-//   fp32 (ds_read_b32, a half reads 2 consecutive rows x 64 B):  64-byte groups, group ^= row & 1
-template <typename E, int RB> __device__ inline int chunk_xor(int row) {
-  if (sizeof(E) == 4) return (row & 1) << 2;
-  if (RB == 128) return ((row >> 1) & 3) << 1;
-  if (RB == 256) return (row & 7) << 1;
-  if (RB == 320) return ((row >> 2) & 1) << 1;
-  return 0;
-}
-
-// transposed MFMA operand: 16 columns starting at col0; rows row0.. (32 for bf16, 16 for fp32).
-// Lane group g supplies k = {4g..4g+3, 16+4g..16+4g+3} (bf16) / {g, 4+g, 8+g, 12+g} (fp32) for BOTH operands.
-template <typename E, int RB> __device__ inline uint4 tr_operand(const unsigned char* img, int row0, int col0, int lane);
-
-template <int RB> __device__ inline uint4 tr_operand_bf16(const unsigned char* img, int row0, int col0, int lane) {
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const int row = row0 + 4 * g + q;
-  const int colb = (col0 + 4 * p) * 2;                         // byte column, multiple of 8
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const unsigned char* a0 = img + row * RB + ((((colb >> 4) ^ chunk_xor<uint16_t, RB>(row))) << 4) + (colb & 15);
-  const unsigned char* a1 = img + (row + 16) * RB + ((((colb >> 4) ^ chunk_xor<uint16_t, RB>(row + 16))) << 4) + (colb & 15);
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1));
-  uint4 r;
-  r.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
-  r.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
-  r.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
-  r.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
-  return r;
-}
-template <int RB> __device__ inline uint4 tr_operand_f32(const unsigned char* img, int row0, int col0, int lane) {
-  const int g = lane >> 4, i = lane & 15;
-  const int colb = (col0 + i) * 4;
-  uint4 r;
-  uint32_t* rp = reinterpret_cast<uint32_t*>(&r);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = row0 + g + 4 * j;
-    rp[j] = *reinterpret_cast<const uint32_t*>(img + row * RB + (((colb >> 4) ^ chunk_xor<float, RB>(row)) << 4) + (colb & 15));
-  }
-  return r;
-}
-template <typename E, int RB> struct TrOp;
-template <int RB> struct TrOp<uint16_t, RB> {
-  __device__ static uint4 get(const unsigned char* img, int row0, int col0, int lane) { return tr_operand_bf16<RB>(img, row0, col0, lane); }
-};
-template <int RB> struct TrOp<half_t, RB> {     // any 16-bit element: ds_read_b64_tr_b16 moves bits
-  __device__ static uint4 get(const unsigned char* img, int row0, int col0, int lane) { return tr_operand_bf16<RB>(img, row0, col0, lane); }
-};
-template <int RB> struct TrOp<float, RB> {
-  __device__ static uint4 get(const unsigned char* img, int row0, int col0, int lane) { return tr_operand_f32<RB>(img, row0, col0, lane); }
-};
 
 // TN = ci columns per workgroup: 64 for KS = 3 (three accumulator sets), 128 for KS = 1 (wave tile
 // TILE_M/2 x 64: fewer LDS bytes per MFMA and half as many re-reads of dy).

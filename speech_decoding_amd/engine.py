@@ -810,5 +810,4 @@ def clip_block_finish(st: ClipBlockStats, row_lse, diag, *, reduction: str = "me
 
 def clip_backward(ctx: ClipCtx, dZt: torch.Tensor, dloss: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dZ = dloss * (diag(c) G^T Y - diag(r) Z)  (gradient of the loss share w.r.t. the local brain embeddings)."""
-    return ops.matmul_tn_typed(ctx.G, ctx.Yt, dZt, ctx.Zt, ctx.rscale, M_rows=ctx.Bm, N_valid=ctx.Bn,
-                               K_cols=ctx.row_elems, pitch=ctx.row_elems, out_scale=dloss, acc_scale=ctx.cscale)
+    return ops.clip_dz(ctx.G, ctx.Yt, ctx.Zt, dZt, ctx.rscale, ctx.cscale, Bm=ctx.Bm, Bn=ctx.Bn, row_elems=ctx.row_elems, out_scale=dloss)

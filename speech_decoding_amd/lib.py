@@ -109,6 +109,8 @@ SIGNATURES = {
     "sda_collate_rows": (i32, [vp, vp, i64, i32, i32, f32, i32, vp]),
     "sda_collate_windows": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "sda_clip_ranks": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "sda_clip_dz_supported": (i32, [i32, i32, i64, i32]),
+    "sda_clip_dz": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     "sda_param_gemm": (i32, [C.POINTER(PgemmArgs), vp]),
     "sda_zero_pad_rows": (i32, [vp, i32, i32, i32, i32, vp]),
     "sda_scalar_mul": (i32, [vp, vp, vp, i32, vp]),

@@ -586,6 +586,17 @@ def matmul_tn_typed(G, Ym, out, sub, rscale, *, M_rows, N_valid, K_cols, pitch, 
     return out
 
 
+def clip_dz(G, Yt, Zt, out, rscale, cscale, *, Bm, Bn, row_elems, out_scale=None):
+    """out[j][k] = out_scale * (cscale[j] * sum_i G[i][j] Yt[i][k] - rscale[j] Zt[j][k]) — the loss's embedding gradient.
+    One GPU's shapes (Bm <= 256, 16-bit) run on the streaming kernel (loss_gemm.hip); anything else on wgrad_gemm's typed output."""
+    if L.load().sda_clip_dz_supported(Bm, Bn, row_elems, dt_code(Yt.dtype)):
+        L.check(L.load().sda_clip_dz(_p(G), G.shape[1], _p(Yt), _p(Zt), _p(out), _p(cscale), _p(rscale), _p(out_scale), Bm, Bn, row_elems,
+                                     dt_code(Yt.dtype), _st()), "clip_dz")
+        return out
+    return matmul_tn_typed(G, Yt, out, Zt, rscale, M_rows=Bm, N_valid=Bn, K_cols=row_elems, pitch=row_elems, out_scale=out_scale,
+                           acc_scale=cscale)
+
+
 def sa_gemm_tables(cos_t: torch.Tensor, sin_t: torch.Tensor):
     """Operand tables of SpatialAttention's two contractions, built from the (K2, C) cos/sin buffers:
     forward  a[o][c] = sum_m Re z[o][m] cos[m][c] + Im z[o][m] sin[m][c]  ->  rows c of [cos | sin] interleaved in m,

@@ -546,3 +546,44 @@ def test_copy3d_strided(ops):
     assert torch.equal(T1[:, 208], col) and float(T1[:, :208].abs().max()) == 0.0
     out = ops.copy3d(torch.empty(270, device=DEV), T1[:, 208])
     assert torch.equal(out, col) and out.is_contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the loss's embedding gradient as a streaming kernel (csrc/loss_gemm.hip)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Bm,Bn,F,T,dtype", [(256, 256, 1024, 360, torch.bfloat16),     # config 2: the benchmarked shape
+                                            (12, 12, 64, 40, torch.bfloat16),           # far below one tile of anything
+                                            (100, 300, 128, 50, torch.float16),          # ragged batch, two column blocks of 256
+                                            (256, 70, 64, 17, torch.float16),
+                                            (33, 64, 192, 9, torch.bfloat16)])
+def test_clip_dz_streaming_kernel_against_fp64(ops, Bm, Bn, F, T, dtype):
+    """dZ[j] = dloss * (cscale[j] * sum_i G[i][j] Y[i] - rscale[j] Z[j]) on row-layout embeddings: against fp64 on the same
+    rounded operands, and against the general kernel it replaces on one GPU (wgrad_gemm's typed output)."""
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(Bm + Bn)
+    Y = torch.randn(Bm, F, T, generator=g)
+    Z = torch.randn(Bn, F, T, generator=g)
+    Yt, Zt = to_rows(ops, Y, dtype), to_rows(ops, Z, dtype)
+    re = L.rows_tp(T) * Yt.shape[1]
+    Gm = torch.zeros((Bm + 1, L.pad_channels(Bn)))
+    Gm[:Bm, :Bn] = torch.randn(Bm, Bn, generator=g) * 0.3
+    Gd = Gm.to(dtype).to(DEV)
+    cs, rs = (torch.rand(Bn, generator=g) + 0.5).to(DEV), (torch.randn(Bn, generator=g) * 0.1).to(DEV)
+    dloss = torch.tensor([1.7], device=DEV)
+    assert L.load().sda_clip_dz_supported(Bm, Bn, re, ops.dt_code(dtype))
+    out = ops.new_rows_uninit(Bn, T, Yt.shape[1], dtype, DEV)
+    ops.clip_dz(Gd, Yt, Zt, out, rs, cs, Bm=Bm, Bn=Bn, row_elems=re, out_scale=dloss)
+    old = ops.new_rows_uninit(Bn, T, Yt.shape[1], dtype, DEV)
+    ops.matmul_tn_typed(Gd, Yt, old, Zt, rs, M_rows=Bm, N_valid=Bn, K_cols=re, pitch=re, out_scale=dloss, acc_scale=cs)
+    Yq, Zq, Gq = q(Y, dtype).double().reshape(Bm, -1), q(Z, dtype).double().reshape(Bn, -1), Gd[:Bm, :Bn].double().cpu()
+    ref = 1.7 * (cs.double().cpu()[:, None] * (Gq.t() @ Yq) - rs.double().cpu()[:, None] * Zq)
+    got = ops.rows_view(out, Bn, F, T).double().cpu().reshape(Bn, -1)
+    was = ops.rows_view(old, Bn, F, T).double().cpu().reshape(Bn, -1)
+    eps = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11               # one rounding of the stored result
+    assert float((got - ref).abs().max()) <= 1.01 * eps * float(ref.abs().max())
+    assert float((got - was).abs().max()) <= 1.01 * eps * float(ref.abs().max())
+    full = out.float().cpu()
+    Tp = L.rows_tp(T)
+    for b in range(Bn):                                                   # pad rows come out as exact zeros, pad channels too
+        assert float(full[b * Tp: b * Tp + L.ROW_PAD].abs().max()) == 0.0
+    assert float(full[:, F:].abs().max()) == 0.0 if full.shape[1] > F else True
