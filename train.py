@@ -137,11 +137,26 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
         tr_loss, tr_ranks = [], []
         brain_encoder.train()
         loss = None
-        for X, Y, subject_idxs in train_batches():
+        def local_shard(batch):
+            X, Y, subject_idxs = batch
             if world > 1:
                 lo, hi = shard_range(X.shape[0], rank, world)
                 X, Y, subject_idxs = X[lo:hi], Y[lo:hi], subject_idxs[lo:hi]
-            loss_func.prefetch(Y, brain_encoder.compute_dtype)     # Y-side work (+ DP all-gather) overlaps the encoder
+            return X, Y, subject_idxs
+
+        # The speech side of the loss does not depend on the encoder: it is started ONE BATCH AHEAD, like a data loader —
+        # batch n + 1's rows are packed (and, under data parallelism, all-gathered: 197 MB per rank at config 3) while batch
+        # n's backward runs, five milliseconds of cover instead of the forward's two and a half.  CLIPLoss keeps two packed
+        # buffers in rotation for exactly this; only the first batch of an epoch is prefetched at its own start.
+        batches = (local_shard(b) for b in train_batches())       # (sharded ONCE per batch: the prefetch is matched by tensor identity)
+        ahead = next(batches, None)
+        first = True
+        while ahead is not None:
+            X, Y, subject_idxs = ahead
+            ahead = next(batches, None)
+            if first:
+                loss_func.prefetch(Y, brain_encoder.compute_dtype)
+                first = False
             Z = brain_encoder(X, subject_idxs)
             loss = loss_func(Y, Z)
             # The reference reads loss.item() and the two accuracies back on the host here, every batch (train.py:194-198):
@@ -151,6 +166,8 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
                 ranks = classifier.ranks(Z, Y)                   # Classifier.forward's ranks, kept on the device
             tr_loss.append(loss.detach())
             tr_ranks.append(ranks)
+            if ahead is not None:
+                loss_func.prefetch(ahead[1], brain_encoder.compute_dtype)
             if args.dataset == "Gwilliams2022":
                 backward_and_step(loss)
         if args.dataset == "Brennan2018" and loss is not None:          # once per epoch, last batch only
