@@ -233,6 +233,7 @@ def main():
     subj_rng = np.random.RandomState(100 + rank)
 
     ranks_acc = []
+    one = torch.ones((), dtype=torch.float32, device=dev)
 
     # Under data parallelism the speech rows of the NEXT batch are packed and all-gathered (197 MB per rank and step at
     # config 3) while THIS step's backward runs, like a data loader that is one batch ahead: five milliseconds of cover
@@ -256,7 +257,7 @@ def main():
             cnt = cnt.cpu()
         ranks_acc.append(cnt)
         opt.zero_grad(set_to_none=True)
-        scaler.scale(loss).backward()
+        scaler.scale(loss).backward(gradient=one)            # (a resident d loss / d loss = 1: autograd would fill a fresh one per step)
         scaler.unscale_(params)
         if world > 1:      # encoder gradients were all-reduced inside backward (overlapped); temp is left
             allreduce_gradients(list(lossf.parameters()) if enc.grads_are_reduced else params)

@@ -222,6 +222,7 @@ class _ClipFn(torch.autograd.Function):
             dist.all_reduce(both, group=group)
             cnt, loss = both[:-1].round().to(torch.int32), both[-1:]
         ctx.cctx, ctx.shape, ctx.dtype, ctx.group = cctx, (B, F, T), dtype, group
+        ctx.set_materialize_grads(False)            # no zero-filled gradient for the (non-differentiable) logits output
         ctx.y_slot = slot
         ctx.z_requires_grad = Z.requires_grad
         _cache_ranks(Y, Z, cnt[col0: col0 + B])
@@ -233,6 +234,8 @@ class _ClipFn(torch.autograd.Function):
         c = ctx.cctx
         B, F, T = ctx.shape
         dZ = None
+        if dloss is None:                           # (the loss itself took no part in what was differentiated)
+            return None, None, None, None
         scale = dloss.to(torch.float32)
         if ctx.z_requires_grad:
             if ctx.y_slot is not None and not ctx.y_slot.valid():

@@ -112,10 +112,11 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
                                   global_batch=int(args.batch_size), T=seq_T)                      # no-op unless fp16
 
     fp16 = scaler.scale_value != 1.0
+    one = torch.ones((), dtype=torch.float32, device=device)       # d loss / d loss, resident (autograd would fill one per step)
 
     def backward_and_step(loss):
         optimizer.zero_grad()
-        scaler.scale(loss).backward()
+        scaler.scale(loss).backward(gradient=one)
         if world > 1:        # (SUM of the still-scaled gradients: every rank then sees the same overflow, or none)
             allreduce_gradients(list(loss_func.parameters()) if brain_encoder.grads_are_reduced else params)
         # fp16 only: an activation gradient that overflowed to inf / NaN must not reach Adam — the finiteness check is a
