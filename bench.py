@@ -103,11 +103,11 @@ def host_cores():
     return max(1, n), model
 
 
-def cpu_baseline(batch: int, budget_s: float = 40.0):
+def cpu_baseline(batch: int, budget_s: float = 75.0):
     """Oracle (CPU restatement of the reference, pinned on the golden fixtures) timed on the host cores, following
     BASELINE.md §3: torch threads = physical cores available to this process, 2 warm-up steps, then timed training
     steps (forward + loss + top-k as a matmul + backward + Adam) at config ② (208 ch, batch 256, 27 subjects) and
-    config ① (60 ch, batch 64, 1 subject); bounded: each config stops after 3 steps or `budget_s` seconds."""
+    config ① (60 ch, batch 64, 1 subject); bounded: each config stops after 5 timed steps or its share of `budget_s` seconds."""
     import torch
     from oracle import brain_oracle as O
     cores, model = host_cores()
@@ -137,19 +137,19 @@ def cpu_baseline(batch: int, budget_s: float = 40.0):
                 P[k].grad = None
             return time.perf_counter() - t0
 
-        one(12, 1)
-        one(12, 2)                                    # 2 warm-up steps (thread pool, allocator, mkldnn primitives)
+        one(12, 1)                                    # 2 warm-up steps (thread pool, allocator, mkldnn primitives): a small one
+        one(B, 2)                                     # and one at the measured size
         t_start = time.perf_counter()
         while len(times) < max_steps and (not times or time.perf_counter() - t_start + times[-1] < budget):
             times.append(one(B, 10 + len(times)))
         return B * len(times) / sum(times), times
 
-    v2, t2 = run(C, S, batch, 3, budget_s)
-    v1, t1 = run(60, 1, 64, 3, budget_s / 2)
+    v2, t2 = run(C, S, batch, 5, budget_s)           # >= 5 timed steps
+    v1, t1 = run(60, 1, 64, 5, budget_s / 4)
     par = [l.strip() for l in torch.__config__.parallel_info().splitlines() if "get_num_threads" in l or "OpenMP" in l or "MKL" in l.upper()]
     return {"value": round(v2, 3), "unit": "segments/s", "cores": cores, "kind": "port",
             "sample": f"config 2 (208ch x 360, batch {batch}, 27 subj): {len(t2)} timed training steps of "
-                      f"{', '.join(f'{x:.1f}' for x in t2)} s after 2 warm-up steps; config 1 (60ch, batch 64, 1 subj): "
+                      f"{', '.join(f'{x:.1f}' for x in t2)} s after 2 warm-up steps (one at full size); config 1 (60ch, batch 64, 1 subj): "
                       f"{len(t1)} steps -> {v1:.2f} segments/s; fp32, step = fwd+loss+top-k(matmul)+bwd+Adam",
             "config1_value": round(v1, 3), "cpu_model": model, "torch_threads": cores,
             "parallel_info": "; ".join(par)[:300]}
