@@ -394,8 +394,8 @@ def matmul_nt_splitk(xm: torch.Tensor, wm: torch.Tensor, M: int, N: int, K: int,
     tile_co = 160 if Np % 160 == 0 else (128 if Np % 128 == 0 else 64)
     tiles = ((M + 127) // 128) * (Np // tile_co)
     ksplit = max(1, min(nslab, (512 + tiles - 1) // tiles))
-    if M * Np < (1 << 17):          # a small product (SpatialAttention's weights: 270 x 256): its slab sum has M * Np threads, each
-        ksplit = min(ksplit, 16)    # walking every slab — keep that walk short (64 slabs: 30 us on the step's start chain)
+    if nslab <= 64:                 # a short contraction (SpatialAttention's weights: 2048 deep, 270 x 256 outputs): the slab sum
+        ksplit = min(ksplit, 16)    # has few threads, each walking every slab — 64 slabs cost 30 us on the step's start chain
     partial = torch.empty((ksplit, M, Np), dtype=torch.float32, device=xm.device)
     a = L.ConvArgs()
     a.x, a.w, a.bias, a.res, a.y, a.y_pre, a.widx, a.stats = _p(xm), _p(wm), None, None, None, None, None, None
