@@ -8,7 +8,7 @@ import numpy as np
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ad = [i for i, r in enumerate(rows) if "adam_multi" in r["Kernel_Name"]]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else -3
+k = int(sys.argv[2]) if len(sys.argv) > 2 else -8      # a steady-state step of the timed region (the last ones are instrumented)
 lo, hi = ad[k - 1] + 1, ad[k] + 1
 t0, t1 = int(rows[lo]["Start_Timestamp"]), int(rows[hi - 1]["End_Timestamp"])
 print(f"step span {(t1 - t0) / 1e3:.1f} us, {hi - lo} kernels")
