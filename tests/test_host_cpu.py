@@ -153,3 +153,55 @@ def test_norm_cache_entries_die_with_their_producer_and_on_inplace_edits():
         if other.data_ptr() == ptr:
             assert cache.get(other, 4) is None
             break
+
+
+def test_fp16_loss_scale_grows_with_global_batch_and_sequence_length():
+    """The gradient entering the encoder shrinks like 1 / (B_global * T): the static fp16 loss scale follows (powers of two), and a
+    step whose gradients overflowed is skipped with the scale halved (GradScaler's rule)."""
+    from speech_decoding_amd.amp import DEFAULT_FP16_SCALE, LossScaler, fp16_scale_for
+    assert fp16_scale_for(256, 360) == DEFAULT_FP16_SCALE == 1024.0
+    assert fp16_scale_for(64, 360) == 1024.0                              # never below the calibration point
+    assert fp16_scale_for(2048, 360) == 8192.0 and fp16_scale_for(4096, 1000) == 65536.0
+    for b, t in [(300, 360), (4096, 360), (512, 1000)]:
+        s = fp16_scale_for(b, t)
+        assert s >= 1024.0 * (b / 256) * (t / 360) > s / 2 and np.log2(s) == int(np.log2(s))
+    assert LossScaler.for_dtype(torch.bfloat16, global_batch=4096, T=1000).scale_value == 1.0
+    assert LossScaler.for_dtype(torch.float16).scale_value == 1024.0
+    sc = LossScaler.for_dtype(torch.float16, global_batch=4096, T=1000)
+    assert sc.scale_value == 65536.0
+    loss = torch.tensor(2.0, requires_grad=True)
+    assert float(sc.scale(loss)) == 2.0 * 65536.0
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.tensor([65536.0, float("inf"), 0.0])
+    assert sc.unscale_([p], check=True) is False
+    sc.update(False)
+    assert sc.scale_value == 32768.0 and sc.skipped_steps == 1
+    p.grad = torch.tensor([32768.0, 0.0, -32768.0])
+    assert sc.unscale_([p], check=True) is True and torch.equal(p.grad, torch.tensor([1.0, 0.0, -1.0]))
+    sc.growth_interval = 2
+    sc.update(True); sc.update(True)
+    assert sc.scale_value == 65536.0
+    none = LossScaler(1.0)
+    none.update(False)
+    assert none.scale_value == 1.0 and none.unscale_([p]) is True
+
+
+def test_row_statistics_merge_equals_a_global_log_sum_exp():
+    """distributed.combine_row_stats — the arithmetic behind the one small all-gather of the data-parallel loss: per-rank (max,
+    sum exp(l - max), positives' logits) over column blocks merge into the row lse over ALL columns and the full diagonal."""
+    from speech_decoding_amd.distributed import combine_row_stats
+    g = torch.Generator().manual_seed(0)
+    B, world = 24, 4
+    logits = torch.randn(B, B, generator=g, dtype=torch.float64) * 5
+    per = B // world
+    stats = []
+    for r in range(world):
+        blk = logits[:, r * per: (r + 1) * per]
+        mx = blk.max(dim=1).values
+        diag = torch.zeros(B, dtype=torch.float64)
+        diag[r * per: (r + 1) * per] = logits.diagonal()[r * per: (r + 1) * per]
+        stats.append(torch.stack([mx, torch.exp(blk - mx[:, None]).sum(dim=1), diag]))
+    lse, diag = combine_row_stats(torch.stack(stats))
+    assert torch.allclose(lse, torch.logsumexp(logits, dim=1), rtol=0, atol=1e-12)
+    assert torch.equal(diag, logits.diagonal())
+    assert torch.allclose(combine_row_stats(torch.stack(stats)[:, :2]), lse)          # without the diagonal: the lse alone
