@@ -27,3 +27,14 @@ def rel_l2(got: torch.Tensor, ref: torch.Tensor) -> float:
     ref = torch.view_as_real(ref) if ref.is_complex() else ref
     got, ref = got.double().reshape(-1).cpu(), ref.double().reshape(-1).cpu()
     return float((got - ref).norm() / (ref.norm() + 1e-300))
+
+
+def temp_grad_terms_norm(logits: torch.Tensor, reduction: str = "mean") -> float:
+    """d loss / d temp = sum_ij g_ij * logits_ij with g = d loss / d logits (the logits are exp(temp) * cosine, so
+    d logits / d temp = logits): a sum whose diagonal (g_ii < 0) and off-diagonal (g_ij > 0) parts largely cancel.  Returns the
+    Frobenius norm of its terms — the scale an error of that sum is to be judged against."""
+    lg = logits.double()
+    B = lg.shape[0]
+    g = torch.softmax(lg, dim=1) + torch.softmax(lg, dim=0) - 2.0 * torch.eye(B, dtype=torch.float64)
+    g = g / (2.0 * B) if reduction == "mean" else g / 2.0
+    return float((g * lg).norm())

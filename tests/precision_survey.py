@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import brain_oracle as O          # noqa: E402   (test infrastructure)
-from tests.parity import operands_as_device_sees_them, rel_l2, round_to      # noqa: E402
+from tests.parity import operands_as_device_sees_them, rel_l2, round_to, temp_grad_terms_norm      # noqa: E402
 from tests.test_e2e_gpu import build, grads_by_state_key, make_args, null_grad   # noqa: E402
 
 DEV = "cuda:0"
@@ -35,7 +35,7 @@ def survey(name, C, S, T, B, dtype, D1=270, D2=320, F=1024, K=32, last4=True, se
     scaler.unscale_(list(enc.parameters()) + list(lossf.parameters()))
     Pr = operands_as_device_sees_them(P, dtype)
     taps = {}
-    lo, Zo, _, go = O.train_step(Pr, torch.tensor([5.1]), round_to(X, dtype), round_to(Y, dtype), subj, loc=loc, drop_centre=7,
+    lo, Zo, lgo, go = O.train_step(Pr, torch.tensor([5.1]), round_to(X, dtype), round_to(Y, dtype), subj, loc=loc, drop_centre=7,
                                  taps=taps)
     # the shared 1x1 conv's bias gradient is an almost exactly cancelling sum: its error against the scale of its TERMS
     k = "subject_block.conv.bias"
@@ -45,7 +45,8 @@ def survey(name, C, S, T, B, dtype, D1=270, D2=320, F=1024, K=32, last4=True, se
           f"|err| / |sum |terms|| = {float(err / terms.abs().sum(dim=(0, 2)).norm()):.3e}   |err| / |grad| = {float(err / go[k].norm()):.3e}")
     print(f"== {name} {dtype}: Z rel_l2 {rel_l2(Z.detach().float(), Zo):.3e}  max/max {float((Z.detach().float().cpu() - Zo).abs().max() / Zo.abs().max()):.3e}"
           f"  loss {float(loss):.5f} vs {float(lo):.5f} (rel {abs(float(loss) - float(lo)) / float(lo):.2e})"
-          f"  temp.grad {float(lossf.temp.grad):.5f} vs {float(go['temp']):.5f}")
+          f"  temp.grad {float(lossf.temp.grad):.5f} vs {float(go['temp']):.5f}"
+          f"  |err| / |terms| = {abs(float(lossf.temp.grad) - float(go['temp'])) / temp_grad_terms_norm(lgo):.3e}")
     worst = []
     for k, g in grads_by_state_key(enc).items():
         ref = go[k]
