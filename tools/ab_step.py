@@ -40,12 +40,12 @@ def timed(n=10):
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
-# variants: name:attr=value,attr=value ... (engine attributes; values are Python literals)
+# variants: name:attr=value,attr=value ... (or ';' between the pairs when a value contains a comma) (engine attributes; values are Python literals)
 specs = sys.argv[2:] or ["base:", "flat_fwd_off:flat_tiles_forward=False"]
 variants = {}
 for spec in specs:
     name, _, rest = spec.partition(":")
-    variants[name] = {kv.split("=")[0]: eval(kv.split("=")[1]) for kv in rest.split(",") if kv}
+    variants[name] = {kv.split("=")[0]: eval(kv.split("=")[1]) for kv in rest.split(";" if ";" in rest else ",") if kv}
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 eng = enc.engine
 eng.main_priority = 0
