@@ -282,17 +282,22 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item()), loss
 
-    for i in range(a.warmup):
+    settle = min(2, a.warmup)                                # warm-up steps kept for AFTER the heap is collected (below)
+    for i in range(a.warmup - settle):
         step(i)
-    ranks_acc.clear()
     # CPython's cyclic collector runs a FULL (generation-2) pass once the objects a freshly built model and its first steps
     # allocated cross its threshold — measured at step ~23 of this loop, 87 ms of host time, then five slower steps
     # (tools/step_warmup.py): 3 ms per step if it lands inside a 20-step timed region.  A long-running training job pays it
     # once per many thousand steps; here the heap is collected and frozen after warm-up (the training driver does the same
     # after its first steps), so the timed region measures steps, not the interpreter's housekeeping.
+    # The collection itself leaves the interpreter cold (the next step takes the host 7 ms to enqueue instead of 4.6): the
+    # last two of the W warm-up steps run after it.
     import gc
     gc.collect()
     gc.freeze()
+    for i in range(a.warmup - settle, a.warmup):
+        step(i)
+    ranks_acc.clear()
     dt, loss = timed(a.steps, a.warmup)                      # the contract number: K clean steps
     cnt = torch.cat([c.to(dev) for c in ranks_acc[-3:]]).float()
     top10 = float((cnt < 10).float().mean())
