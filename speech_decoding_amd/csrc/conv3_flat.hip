@@ -171,7 +171,7 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
     else { if (wid + 4 * i < S::XP) issue_x(s, wid + 4 * i); else issue_w(s, wid + 4 * i); }
   };
 
-  const int nslab = c.nslab;
+  const int nslab = (a.flags & 512) ? 1 : c.nslab;          // flag 512 (diagnostic): one K-step only — the epilogue's time (results are garbage)
   static_for<0, S::NP>([&](auto ic) { issue(0, ic); });      // K-step 0 whole; later steps group by group
   unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, sAB = 0, sBC = 0, sCD = 0, sDA = 0, nph = 0;
   auto now = [&]() {
