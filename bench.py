@@ -282,7 +282,7 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item()), loss
 
-    settle = min(2, a.warmup)                                # warm-up steps kept for AFTER the heap is collected (below)
+    settle = min(4, max(0, a.warmup - 1))                    # warm-up steps kept for AFTER the heap is collected (below)
     for i in range(a.warmup - settle):
         step(i)
     # CPython's cyclic collector runs a FULL (generation-2) pass once the objects a freshly built model and its first steps
@@ -290,8 +290,9 @@ def main():
     # (tools/step_warmup.py): 3 ms per step if it lands inside a 20-step timed region.  A long-running training job pays it
     # once per many thousand steps; here the heap is collected and frozen after warm-up (the training driver does the same
     # after its first steps), so the timed region measures steps, not the interpreter's housekeeping.
-    # The collection itself leaves the interpreter cold (the next step takes the host 7 ms to enqueue instead of 4.6): the
-    # last two of the W warm-up steps run after it.
+    # The collection itself leaves the interpreter cold (the next step takes the host 7 ms to enqueue instead of 4.6, and the
+    # four after it are 0.1-0.4 ms slow on the GPU side: tools/step_series.py N SETTLE): it runs after the FIRST warm-up step —
+    # by then the model, the workspaces and every cached launch descriptor exist — and up to four of the W warm-up steps follow it.
     import gc
     gc.collect()
     gc.freeze()

@@ -27,6 +27,9 @@ def step():
 for _ in range(8): step()
 torch.cuda.synchronize(); gc.collect(); gc.freeze()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+SETTLE = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # steps between the heap collection and the measured loop (bench.py: 2)
+for _ in range(SETTLE): step()
+if SETTLE: torch.cuda.synchronize()
 evs, host = [], []
 e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
 for _ in range(N):
