@@ -91,6 +91,40 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
   }
 }
 
+// The same for T % 4 == 0 and a 16-byte aligned source: 16-byte loads along t, 16-byte stores along c (8 channels of a 16-bit
+// type per lane instead of one: a wave's store covers 8 rows x 128 B instead of 128 B).  Same values, same rounding.
+template <typename E>
+__global__ __launch_bounds__(256) void pack_rows_vec_kernel(const float* __restrict__ src, E* __restrict__ dst,
+                                                            int C, int T, int Cp, int one_ch) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = threadIdx.x + 256 * k, cc = idx >> 4, t4 = (idx & 15) * 4;
+    const int c = c0 + cc, t = t0 + t4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < T) {                                       // (T % 4 == 0: the four are inside or outside together)
+      if (c < C) v = *reinterpret_cast<const float4*>(src + ((size_t)b * C + c) * T + t);
+      else if (c == one_ch) v = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    tile[cc][t4] = v.x; tile[cc][t4 + 1] = v.y; tile[cc][t4 + 2] = v.z; tile[cc][t4 + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int item = threadIdx.x + 256 * k, chunk = item & 7, rr = item >> 3;
+    const int t = t0 + rr;
+    if (t < T) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tile[chunk * 8 + j][rr];
+      E* out = dst + ((size_t)b * rows_tp(T) + PAD + t) * Cp + c0 + chunk * 8;
+      if constexpr (sizeof(E) == 4) { Vec16<E>::store(out, v); Vec16<E>::store(out + 4, v + 4); }
+      else Vec16<E>::store(out, v);
+    }
+  }
+}
+
 template <typename E>
 __global__ __launch_bounds__(256) void unpack_rows_kernel(const E* __restrict__ src, float* __restrict__ dst,
                                                           int C, int T, int Cp) {
@@ -817,7 +851,11 @@ extern "C" int sda_pack_rows(const float* src, void* dst, int B, int C, int T, i
   if (!src || !dst || Cp % 64 || C > Cp || B < 1) { set_error("pack_rows: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((T + 63) / 64, Cp / 64, B);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_rows_kernel<E>, grid, dim3(256), 0, st, src, (E*)dst, C, T, Cp, -1));
+  if (T % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_rows_vec_kernel<E>, grid, dim3(256), 0, st, src, (E*)dst, C, T, Cp, -1));
+  } else {
+    SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_rows_kernel<E>, grid, dim3(256), 0, st, src, (E*)dst, C, T, Cp, -1));
+  }
   return check_launch("pack_rows");
 }
 
@@ -828,7 +866,11 @@ extern "C" int sda_pack_rows_ones(const float* src, void* dst, int B, int C, int
   }
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((T + 63) / 64, Cp / 64, B);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_rows_kernel<E>, grid, dim3(256), 0, st, src, (E*)dst, C, T, Cp, ones_channel));
+  if (T % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_rows_vec_kernel<E>, grid, dim3(256), 0, st, src, (E*)dst, C, T, Cp, ones_channel));
+  } else {
+    SDA_DISPATCH(dtype, hipLaunchKernelGGL(pack_rows_kernel<E>, grid, dim3(256), 0, st, src, (E*)dst, C, T, Cp, ones_channel));
+  }
   return check_launch("pack_rows_ones");
 }
 
