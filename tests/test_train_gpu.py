@@ -12,6 +12,17 @@ pytestmark = pytest.mark.gpu
 from oracle import brain_oracle as O      # noqa: E402
 
 
+# the fp32 CPU oracle loop of a curve test does not depend on the compute dtype under test: run it once per module, not once per
+# parametrisation (it is most of those tests' time)
+_ORACLE_CURVES = {}
+
+
+def oracle_curve(key, make):
+    if key not in _ORACLE_CURVES:
+        _ORACLE_CURVES[key] = make()
+    return _ORACLE_CURVES[key]
+
+
 def tiny_args(dataset):
     from speech_decoding_amd import load_config
     loc = O.synthetic_positions(12, seed=7)
@@ -128,8 +139,11 @@ def test_200_step_training_curve_of_16bit_paths_tracks_the_fp32_oracle(dtype, tm
     torch.manual_seed(0)
     init = {k: v.clone() for k, v in BrainEncoder(args).state_dict().items()}
     data_cpu = T.SyntheticSegments(args, 200, "cpu", seed=1234)
-    np.random.seed(0)
-    want, _ = oracle_loop(args, loc, init, data_cpu, updates=10)
+
+    def run_oracle():
+        np.random.seed(0)
+        return oracle_loop(args, loc, init, data_cpu, updates=10)[0]
+    want = oracle_curve("toy widths, 200 steps", run_oracle)
     torch.manual_seed(0)
     np.random.seed(0)
     hist, enc, lossf = T.run(args, log=lambda *a: None)
@@ -174,8 +188,11 @@ def test_short_training_curve_at_real_widths_tracks_the_fp32_oracle(dtype, tmp_p
     init = {k: v.clone() for k, v in BrainEncoder(args).state_dict().items()}
     data_cpu = T.SyntheticSegments(args, 80, "cpu", seed=1234)
     assert tuple(data_cpu.test_batch()[0].shape[1:]) == (208, 360)
-    np.random.seed(0)
-    want, _ = oracle_loop(args, loc, init, data_cpu, updates=6)
+
+    def run_oracle():
+        np.random.seed(0)
+        return oracle_loop(args, loc, init, data_cpu, updates=6)[0]
+    want = oracle_curve("real widths, 24 steps", run_oracle)
     torch.manual_seed(0)
     np.random.seed(0)
     hist, enc, lossf = T.run(args, log=lambda *a: None)
