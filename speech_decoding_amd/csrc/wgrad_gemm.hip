@@ -102,7 +102,24 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
       tile = rem % ntile;
     }
   }
-  const int n_tile = tile % n_n, m_tile = tile / n_n;
+  int n_tile = tile % n_n, m_tile = tile / n_n;
+  if (a.nseg == 1 && n_m > 1) {
+    // one segment (the typed-output matrix mode: dZ = G^T Y with thousands of column tiles): the n_m row tiles of a column
+    // tile stream the same x rows — deal them to the same XCD side by side (blocks i and i + 8), so those rows come from HBM
+    // once and from that XCD's L2 the other n_m - 1 times (tile-major order sent every x row to HBM n_m times, a whole
+    // pass of the grid apart)
+    const int grp = 8 * n_m, full2 = (int)(gridDim.x / grp) * grp;
+    bid = blockIdx.x;
+    if (bid < full2) {
+      const int base = bid / grp, rem = bid - base * grp;
+      n_tile = base * 8 + (rem & 7);
+      m_tile = rem >> 3;
+    } else {
+      const int rem = bid - full2;
+      n_tile = full2 / n_m + rem / n_m;
+      m_tile = rem % n_m;
+    }
+  }
   const int co0 = m_tile * TILE_M, ci0 = n_tile * WG_TN;
   const int halo = (KS == 3) ? a.dil : 0;
   const int x_pieces = ((KT + 2 * halo) * G::RB_N + 1023) >> 10;
