@@ -67,28 +67,60 @@ constexpr int F_LDS = F_MAIN;
 static_assert(F_EP_BYTES + FEpi<4>::RED_BYTES <= F_LDS && F_EP_BYTES + FEpi<8>::RED_BYTES <= F_LDS, "epilogue staging must fit");
 static_assert(2 * F_LDS <= 160 * 1024, "two workgroups per CU");
 
-// LDS-DMA schedule of a tile with MREP 16-row fragments per wave (R = 32 * MREP rows): per K-step XP input pieces + 30
-// weight pieces = 4 * NP, wave w takes pieces j = w + 4i (i < NP) in need order (input, tap 0, tap 1, tap 2) and issues
-// them for K-step s+1 during the three phases of K-step s in groups of (4, G1, G2).
+// LDS-DMA schedule of a tile with MREP 16-row fragments per wave (R = 32 * MREP rows).  Everything a tap phase reads has
+// landed — and is visible to every wave — ONE PHASE EARLY, so a phase's weight fragments and its first input fragment are
+// read at the end of the phase before it, in front of the barrier, and the MFMAs start the moment the barrier opens.
+// The stream of pieces issued during K-step s, in need order:
+//   [x(s+1): XP] [tap 1 (s+1): 10] [tap 2 (s+1): 10] [tap 0 (s+2): 10]  = 4 * NP pieces, wave w takes j = w + 4 i (i < NP),
+// in groups of (G0, G1, G2) during the three tap phases, between the MFMA rows.
+//   * landed one phase early: a slab read in phase p must be issued by phase p - 3 (the counted wait at the top of phase
+//     p - 1 leaves only the pieces of phase p - 2 in flight): x(s+1) and tap 0 (s+1) by phase (s, 0), tap 1 (s+1) by (s, 1),
+//     tap 2 (s+1) by (s, 2);
+//   * write-after-read: a tap slab goes into the ring slot of the slab four phases older, whose fragments were all read
+//     (and waited for, lgkmcnt(0)) in front of THAT phase's barrier — so the slot is free from that barrier on: tap 1 (s+1)
+//     from phase (s, 0), tap 2 (s+1) from (s, 1), tap 0 (s+2) from (s, 2); x(s+1) overwrites x(s-1), last read in phase
+//     (s-1, 2): free from (s, 0).
 template <int MREP> struct FSched {
   static constexpr int R = 32 * MREP;
   static constexpr int XP = (R + 2 * PAD) / 16;
   static constexpr int NP = (XP + 3 * F_WP) / 4;
-  static constexpr int G0 = 4, G1 = (NP - 4 + 1) / 2, G2 = NP - 4 - G1;
+  static constexpr int G0 = (XP + 3) / 4, G1 = (XP + 2 * F_WP) / 4 - G0, G2 = NP - G0 - G1;
   static_assert((XP + 3 * F_WP) % 4 == 0, "pieces must divide evenly over the four waves");
-  // what may still be in flight when a phase starts (everything older has landed): tap 0 needs the groups issued two and
-  // three phases ago (only the previous phase's G2 pieces may be pending); taps 1 and 2 need pieces up to the previous
-  // K-step's last group, after which only the 4 pieces of the phase just before were issued (tap 1) or 4 + G1 (tap 2)
-  static constexpr int WAIT0 = G2, WAIT1 = G0, WAIT2 = G0;
-  // write-after-read: a tap slab goes into the ring slot read three phases earlier, so no piece of tap 1 may be issued in
-  // group 0 (its slot is being read in that very phase) and none of tap 2 before group 2
-  static_assert(4 * G0 <= XP + F_WP, "group 0 must hold input and tap-0 pieces only");
-  static_assert(4 * (G0 + G1) <= XP + 2 * F_WP, "group 1 must not reach tap 2");
+  static_assert(4 * G0 >= XP && 4 * G0 <= XP + F_WP, "group 0: all of x(s+1), nothing of tap 2");
+  static_assert(4 * (G0 + G1) >= XP + F_WP && 4 * (G0 + G1) <= XP + 2 * F_WP, "group 1: the rest of tap 1, nothing of tap 0 (s+2)");
+  static_assert(G0 <= MREP && G1 <= MREP && G2 <= MREP, "one piece per MFMA row at most");
+  // pieces that may still be in flight at the top of a phase = the group issued during the phase before it
+  static constexpr int WAIT0 = G2, WAIT1 = G0, WAIT2 = G1;
+  // tile prologue: tap 0 (0) first (pieces j = w + 4 i < 10), then the stream of "K-step -1"; P(0, 0)'s operands (x(0),
+  // tap 0 (0)) are behind everything but that stream's groups 1 and 2
+  static constexpr int WAITP = G1 + G2;
 };
 
-template <int N> __device__ inline void wait_vmcnt_lit();
-template <> __device__ inline void wait_vmcnt_lit<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-template <> __device__ inline void wait_vmcnt_lit<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+template <int N> __device__ __forceinline__ void wait_vmcnt_lit() {
+  static_assert(N >= 0 && N <= 8, "add the literal");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+// One LDS-DMA piece, lean form: wave-uniform 64-bit source base (an SGPR pair the caller computed with scalar arithmetic
+// well ahead — no VALU-written SGPR feeds the load, so no s_nop 4), ONE per-lane byte offset register, and M0 written in
+// the statement that reads it (nothing else in these kernels keeps a value in M0, so it is not saved).
+// PADDED = true opens with s_nop 4: for the places (a tile's prologue) where hipcc may hand the statement a scalar it has
+// just reloaded from a spill lane (v_readlane: a VALU write).  tools/check_dma_hazard.py walks the listing for unpadded ones.
+template <bool PADDED = false>
+__device__ __forceinline__ void lds_dma16_lean(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  if constexpr (PADDED)
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 
 // MFMA "weights" fragment of a 16-column identity block: B[col][k] = 1 where k == 16 * half + col, as mma16<E> reads
 // it (lane (lr = col, lq) holds k = 8 lq + j in element j; fp32: k = 4 lq + j, one 16-wide block per slab, half = 0).
@@ -118,7 +150,7 @@ struct FTileCtx {            // per-workgroup constants shared by all its tiles
 // STAMP (diagnostic build, never the product path): s_memtime stamps split every tap phase of the K loop into
 // [barrier exit -> operands in registers] [MFMA + DMA issue] [vmcnt wait] [barrier]; the four cycle sums of wave 0 go to
 // st[0..3] (+ the phase count in st[4]).  Shares are meaningful, the run time of this build is not.
-template <typename E, bool BN, int MREP, bool RESX, bool STAMP = false, bool GLU = false>
+template <typename E, bool BN, int MREP, bool RESX, int DIAG = 0, bool GLU = false>
 __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char* smem, const FTileCtx& c, const long f0,
                                           const int stat_row, unsigned long long* st = nullptr) {
   constexpr int SLAB = ROW_B / (int)sizeof(E);
@@ -126,8 +158,8 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
   constexpr int CH = Vec16<E>::N;
   using G = FEpi<CH>;
   using S = FSched<MREP>;
+  constexpr bool STAMP = DIAG == 1;          // DIAG (diagnostic builds): 1 stamps, 2 no LDS-DMA inside the K loop, 3 no LDS-DMA and no fragment reads either
   constexpr int R = S::R;
-  const int tid = c.tid, lane = c.lane, wid = c.wid, wave_m = c.wave_m, wave_n = c.wave_n, lr = c.lr, lq = c.lq;
   const int co0 = c.co0, dil = a.dil, Tp = c.Tp;
   const long lds_row0 = f0 - dil;                            // buffer row of LDS input row 0
   const E* __restrict__ xg = reinterpret_cast<const E*>(a.x);
@@ -139,40 +171,87 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
 #pragma unroll
     for (int n = 0; n < F_NREP; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // piece j of K-step s: j < XP an input piece, else weight piece (j - XP) % 10 of tap (j - XP) / 10.  A piece is one
-  // wave-instruction: 64 lanes x 16 B land lane-linearly in LDS (16 rows x 64 B); the bank swizzle goes on the SOURCE
-  // chunk (bit 2 of the row: the same for every piece, pieces start at multiples of 16 rows).  A piece's first row is
-  // wave-uniform, so its address is a scalar base + ONE per-lane offset register: no per-piece vector arithmetic, no
-  // 64-bit pointers for the compiler to hoist and spill.  Pieces that would start outside the buffer are moved inside as
-  // a whole: they only feed rows that are never stored (the first sample's leading padding / rows past the last sample).
-  const uint32_t xvoff = (uint32_t)(((size_t)c.prow * a.x_pitch + (size_t)((c.pchunk ^ sw64(c.prow)) * PER16)) * sizeof(E));
-  const uint32_t wvoff = (uint32_t)(((size_t)c.prow * a.w_pitch + (size_t)((c.pchunk ^ sw64(c.prow)) * PER16)) * sizeof(E));
+  {   // ==== K loop (a scope of its own: none of its per-thread values lives on into the epilogue, and vice versa — below)
+  // (per-thread values re-derived per tile from a lane index hipcc cannot see through: they die with the K loop instead of
+  // being carried — i.e. spilled — across the epilogue and the other tile size's code)
+  int lane_k = c.lane;
+  asm volatile("" : "+v"(lane_k));
+  const int wid = c.wid, wave_m = c.wave_m, wave_n = c.wave_n, lr = lane_k & 15, lq = lane_k >> 4;
+  const int k_prow = lane_k >> 2, k_pchunk = lane_k & 3;
+  // ---- LDS-DMA pieces (FSched).  A piece is one wave-instruction: 64 lanes x 16 B land lane-linearly in LDS (16 rows x 64 B);
+  // the bank swizzle goes on the SOURCE chunk (bit 2 of the row: the same for every piece, pieces start at multiples of 16
+  // rows).  A piece's first row is wave-uniform, so its address is a scalar base (computed once per tile, with scalar
+  // arithmetic) + ONE per-lane offset register that also carries the K-step's channel offset: no per-piece address
+  // arithmetic at all inside the K loop.  x_pitch == w_pitch (supports()), so input and weight pieces share that register.
+  // Pieces that would start outside the buffer are moved inside as a whole: they only feed rows that are never stored
+  // (the first sample's leading padding / rows past the last sample).
+  const uint32_t voff0 = (uint32_t)(((size_t)k_prow * a.x_pitch + (size_t)((k_pchunk ^ sw64(k_prow)) * PER16)) * sizeof(E));
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-  const bool fake_src = a.flags & 8;                        // diagnostic: every piece reads the same 16 rows (no memory-system load)
-  auto issue_x = [&](int s, int j) {
-    long srow = lds_row0 + j * 16;
-    srow = srow < 0 ? 0 : (srow > a.x_rows_limit - 16 ? a.x_rows_limit - 16 : srow);
-    if (fake_src) { srow = 0; s = 0; }
-    lds_dma16_sv(xg + (size_t)srow * a.x_pitch + (size_t)s * SLAB, xvoff, lds_base + (s & 1) * F_XB + j * 1024);
-  };
-  auto issue_w = [&](int s, int j) {
-    const int q = j - S::XP;
-    const int tap = q / F_WP, qq = q - tap * F_WP;
-    if (fake_src) { lds_dma16_sv(wg, wvoff, lds_base + 2 * F_XB + ((3 * s + tap) & 3) * F_WB + qq * 1024); return; }
-    lds_dma16_sv(wg + ((size_t)tap * a.Cout_p + co0 + qq * 16) * a.w_pitch + (size_t)s * SLAB, wvoff,
-                 lds_base + 2 * F_XB + ((3 * s + tap) & 3) * F_WB + qq * 1024);
-  };
-  // i-th piece of this wave for K-step s (j = wid + 4 i): the kind is known at compile time except where the four
-  // waves' pieces straddle the input / weight boundary
-  auto issue = [&](int s, auto ic) {
+  // stream piece i of this wave (j = wid + 4 i): kind 0 = x(s+1), 1..2 = tap 1..2 of K-step s+1, 3 = tap 0 of K-step s+2
+  // (its source base already carries the extra K-step).  Source bases (scalar pairs, fixed for the tile):
+  const char* pbase[S::NP];
+  static_for<0, S::NP>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    if constexpr (4 * i + 3 < S::XP) issue_x(s, wid + 4 * i);
-    else if constexpr (4 * i >= S::XP) issue_w(s, wid + 4 * i);
-    else { if (wid + 4 * i < S::XP) issue_x(s, wid + 4 * i); else issue_w(s, wid + 4 * i); }
+    const int j = wid + 4 * i;
+    if (j < S::XP) {
+      long srow = lds_row0 + j * 16;
+      srow = srow < 0 ? 0 : (srow > a.x_rows_limit - 16 ? a.x_rows_limit - 16 : srow);
+      pbase[i] = reinterpret_cast<const char*>(xg + (size_t)srow * a.x_pitch);
+    } else {
+      const int q = j - S::XP, kind = 1 + q / F_WP, qq = q - (kind - 1) * F_WP;
+      const int tap = kind == 3 ? 0 : kind;
+      pbase[i] = reinterpret_cast<const char*>(wg + ((size_t)tap * a.Cout_p + co0 + qq * 16) * a.w_pitch) + (kind == 3 ? ROW_B : 0);
+    }
+  });
+  // LDS destinations: the buffers the stream of K-step s writes — x buffer (s+1) & 1, ring slots (3 (s+1) + tap) & 3 and
+  // (3 (s+2)) & 3 — as four rotating scalars that already carry this wave's share (wid * 1024) of the piece index, so a
+  // piece's destination is one of them plus a compile-time constant
+  uint32_t xdst, wdst1, wdst2, wdst0;
+  const uint32_t lds_w = lds_base + (uint32_t)wid * 1024u;
+  auto set_dst = [&](int s) {
+    xdst = lds_w + (uint32_t)((s + 1) & 1) * F_XB;
+    wdst1 = lds_w + 2 * F_XB + (uint32_t)((3 * s + 4) & 3) * F_WB;
+    wdst2 = lds_w + 2 * F_XB + (uint32_t)((3 * s + 5) & 3) * F_WB;
+    wdst0 = lds_w + 2 * F_XB + (uint32_t)((3 * s + 6) & 3) * F_WB;
   };
+  uint32_t kvoff = voff0;                                  // per-lane offset incl. the channel offset of K-step s+1
+  // issue stream piece i.  (The last K-step but one has no tap 0 (s+2) to fetch; it issues those ten pieces all the same —
+  // they read the 64 bytes behind each weight row's last slab, i.e. the head of the next row, always inside the tap-0 block
+  // of the operand, into a ring slot nothing reads any more — so that every K-step but the last is the same code with the
+  // same counts.)
+  auto issue = [&](auto ic, auto padc) {
+    constexpr int i = decltype(ic)::value;
+    constexpr bool PD = decltype(padc)::value;
+    constexpr int jlo = 4 * i, jhi = 4 * i + 3;
+    constexpr int b1 = S::XP, b2 = S::XP + F_WP, b3 = S::XP + 2 * F_WP;      // kind boundaries in j
+    // piece index inside its buffer minus wid, times 1024, per kind (x: j; tap pieces: j - boundary)
+    constexpr int cx = 4 * i * 1024, c1 = (4 * i - b1) * 1024, c2 = (4 * i - b2) * 1024, c3 = (4 * i - b3) * 1024;
+    const int j = wid + 4 * i;
+    if constexpr (jlo >= b3) lds_dma16_lean<PD>(pbase[i], kvoff, wdst0 + (uint32_t)c3);
+    else if constexpr (jhi >= b3) lds_dma16_lean<PD>(pbase[i], kvoff, j < b3 ? wdst2 + (uint32_t)c2 : wdst0 + (uint32_t)c3);   // tap 2 | tap 0 (s+2), by wave
+    else if constexpr (jlo >= b2) lds_dma16_lean<PD>(pbase[i], kvoff, wdst2 + (uint32_t)c2);
+    else if constexpr (jhi >= b2) lds_dma16_lean<PD>(pbase[i], kvoff, j < b2 ? wdst1 + (uint32_t)c1 : wdst2 + (uint32_t)c2);
+    else if constexpr (jlo >= b1) lds_dma16_lean<PD>(pbase[i], kvoff, wdst1 + (uint32_t)c1);
+    else if constexpr (jhi >= b1) lds_dma16_lean<PD>(pbase[i], kvoff, j < b1 ? xdst + (uint32_t)cx : wdst1 + (uint32_t)c1);
+    else lds_dma16_lean<PD>(pbase[i], kvoff, xdst + (uint32_t)cx);
+  };
+  using TrueC = std::integral_constant<bool, true>;
+  using FalseC = std::integral_constant<bool, false>;
 
   const int nslab = (a.flags & 512) ? 1 : c.nslab;          // flag 512 (diagnostic): one K-step only — the epilogue's time (results are garbage)
-  static_for<0, S::NP>([&](auto ic) { issue(0, ic); });      // K-step 0 whole; later steps group by group
+  // ---- tile prologue: tap 0 of K-step 0, then the stream of "K-step -1" (x(0), taps 1 and 2 of K-step 0, tap 0 of K-step 1)
+  {
+    const uint32_t w00 = lds_base + 2 * F_XB;              // slot (3 * 0 + 0) & 3
+#pragma unroll
+    for (int i = 0; i < (F_WP + 3) / 4; ++i) {
+      const int qq = wid + 4 * i;
+      if (qq < F_WP) lds_dma16_lean<true>(reinterpret_cast<const char*>(wg + ((size_t)co0 + qq * 16) * a.w_pitch), voff0, w00 + (uint32_t)qq * 1024u);
+    }
+  }
+  set_dst(-1);
+  static_for<0, S::NP>([&](auto ic) { issue(ic, TrueC{}); });
+  wait_vmcnt_lit<S::WAITP>();
+  __builtin_amdgcn_s_barrier();
   unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, sAB = 0, sBC = 0, sCD = 0, sDA = 0, nph = 0;
   auto now = [&]() {
     unsigned long long t;
@@ -181,58 +260,87 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
     __builtin_amdgcn_sched_barrier(0);
     return t;
   };
-  for (int s = 0; s < nslab; ++s) {
-    const bool more = s + 1 < nslab && !(a.flags & 16);      // flag 16 (diagnostic): no DMA inside the K loop (results are garbage)
+  // operands of phase (0, 0): the wave's five weight fragments and its first input fragment
+  const int wrow = wave_n * (F_CO / 2) + lr;
+  const int xrow0 = wave_m * (R / 2) + lr;
+  uint4 bf[F_NREP];
+  uint4 af;
+  auto load_b = [&](int slot) {
+    const unsigned char* ws = smem + 2 * F_XB + slot * F_WB;
+#pragma unroll
+    for (int n = 0; n < F_NREP; ++n) bf[n] = *reinterpret_cast<const uint4*>(ws + lds_sw64(wrow + n * 16, lq));
+  };
+  load_b(0);
+  af = *reinterpret_cast<const uint4*>(smem + lds_sw64(xrow0, lq));
+
+  // One K-step = three tap phases.  MODE 0: every K-step but the last (issues the whole stream of this K-step), 2: the last
+  // (issues nothing, waits for everything).
+  auto kstep = [&](const int s, auto modec) {
+    constexpr int MODE = decltype(modec)::value;
     const unsigned char* xs = smem + (s & 1) * F_XB;
+    if constexpr (MODE < 2) { set_dst(s); kvoff += ROW_B; }
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap) {
-      // everything this phase reads has landed once all but this wave's youngest WAIT pieces are done ...
-      if (more) {
-        if (tap == 0) wait_vmcnt_lit<S::WAIT0>();
-        else if (tap == 1) wait_vmcnt_lit<S::WAIT1>();
-        else wait_vmcnt_lit<S::WAIT2>();
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      // this phase's operands are in registers (or on their way: lgkmcnt below); what the NEXT phase reads has landed once
+      // all but this wave's youngest WAIT pieces are done ...
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and our reads of the slots this phase's pieces overwrite are done
+      if constexpr (MODE == 2) { if (tap < 2) wait_vmcnt_lit<0>(); }
+      else if (tap == 0) wait_vmcnt_lit<S::WAIT0>();
+      else if (tap == 1) wait_vmcnt_lit<S::WAIT1>();
+      else wait_vmcnt_lit<S::WAIT2>();
       if constexpr (STAMP) { tD = now(); if (nph) sCD += tD - tC; }
-      __builtin_amdgcn_s_barrier();                          // ... for every wave; the slots written below are consumed
-      if constexpr (STAMP) { tA = now(); if (nph) sDA += tA - tD; }
-      const unsigned char* ws = smem + 2 * F_XB + ((3 * s + tap) & 3) * F_WB;
-      uint4 bf[F_NREP];
-      const int wrow = wave_n * (F_CO / 2) + lr;
-#pragma unroll
-      for (int n = 0; n < F_NREP; ++n) bf[n] = *reinterpret_cast<const uint4*>(ws + lds_sw64(wrow + n * 16, lq));
-      const int xrow = wave_m * (R / 2) + lr + tap * dil;
-      // This phase's DMA pieces go BETWEEN the MFMA groups (an LDS-DMA issue costs ~100 cycles of the wave's issue slot,
-      // free while the matrix pipe works through the MFMAs queued before it), and the next input fragment is read
-      // before the current one's MFMAs: hipcc will not move an LDS read across the asm statements.
-      constexpr int every = MREP / 4;
-      uint4 af = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow, lq));
-      if constexpr (STAMP) { tB = now(); sAB += tB - tA; }
+      __builtin_amdgcn_s_barrier();                          // ... for every wave
+      if constexpr (STAMP) { tA = now(); if (nph) sDA += tA - tD; tB = tA; }
+      const int xrow = xrow0 + tap * dil;
+      // next phase: (s, tap + 1) or (s + 1, 0)
+      const bool last_phase = MODE == 2 && tap == 2;
+      const unsigned char* xs_n = tap == 2 ? smem + ((s + 1) & 1) * F_XB : xs;
+      const int xrow_n = xrow0 + (tap == 2 ? 0 : (tap + 1) * dil);
       static_for<0, MREP>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         uint4 af_next = af;
-        if constexpr (m + 1 < MREP) af_next = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow + (m + 1) * 16, lq));
+        if constexpr (DIAG == 3) { asm volatile("" : "+v"(af_next.x)); }
+        else if constexpr (m + 1 < MREP) af_next = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow + (m + 1) * 16, lq));
+        else { if (!last_phase) af_next = *reinterpret_cast<const uint4*>(xs_n + lds_sw64(xrow_n, lq)); }
 #pragma unroll
         for (int n = 0; n < F_NREP; ++n) acc[m][n] = mma16<E>(af, bf[n], acc[m][n]);
-        if constexpr ((m % every) == every - 1) {
-          constexpr int k = m / every;                       // 0..3: this phase's k-th piece
-          if (more) {
-            if (tap == 0) { if constexpr (k < S::G0) issue(s + 1, std::integral_constant<int, k>{}); }
-            else if (tap == 1) { if constexpr (k < S::G1) issue(s + 1, std::integral_constant<int, S::G0 + k>{}); }
-            else { if constexpr (k < S::G2) issue(s + 1, std::integral_constant<int, S::G0 + S::G1 + k>{}); }
-          }
+        // this phase's DMA pieces go BETWEEN the MFMA rows (the wave's issue slot is free while the matrix pipe works
+        // through the MFMAs queued before it)
+        if constexpr (MODE < 2 && DIAG < 2) {
+          if (tap == 0) { if constexpr (m < S::G0) issue(std::integral_constant<int, m>{}, FalseC{}); }
+          else if (tap == 1) { if constexpr (m < S::G1) issue(std::integral_constant<int, S::G0 + m>{}, FalseC{}); }
+          else { if constexpr (m < S::G2) issue(std::integral_constant<int, S::G0 + S::G1 + m>{}, FalseC{}); }
         }
         af = af_next;
       });
+      // the next phase's weight fragments, in front of its barrier (their slab landed a phase ago)
+      // (behind a scheduling fence: the fragments go into the registers the last MFMA row has just read — without it hipcc
+      // overlaps the two sets, 20 registers the kernel does not have)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DIAG != 3) { if (!last_phase) load_b((3 * s + tap + 1) & 3); }
       if constexpr (STAMP) { tC = now(); sBC += tC - tB; ++nph; }
     }
+  };
+  {
+    int s = 0;
+    for (; s + 1 < nslab; ++s) kstep(s, std::integral_constant<int, 0>{});
+    kstep(s, std::integral_constant<int, 2>{});
   }
   if constexpr (STAMP) {
     if (st && c.tid == 0) { st[0] += sAB; st[1] += sBC; st[2] += sCD; st[3] += sDA; st[4] += nph; }
   }
 
+  }   // ==== end of the K loop's scope
   // ------------------------------------------------------------------ epilogue
+  // Every per-thread value of the epilogue is derived HERE from a thread index hipcc cannot see through: otherwise it
+  // computes them at kernel entry and keeps them in registers across the K loop, where 160 accumulators + 28 fragment
+  // registers leave no room — the fragments were spilled INSIDE the loop (and a compiler-generated wait for a scratch
+  // reload is vmcnt(0): it drains the LDS-DMA pipeline).
+  int tid_e = c.tid;
+  asm volatile("" : "+v"(tid_e));
+  const int tid = tid_e, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wave_m = wid >> 1, wave_n = wid & 1;
+  const int lr = lane & 15, lq = lane >> 4, e_prow = lane >> 2, e_pchunk = lane & 3;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   if (a.flags & 256) {        // diagnostic: skip the epilogue, keep the accumulators live
     float keep = 0.f;
 #pragma unroll
@@ -285,7 +393,7 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
   constexpr int RES_OFF = F_EP_BYTES + FEpi<8>::RED_BYTES;
   static_assert(!RES_LDS || RES_OFF + F_EP_ROWS * F_CO * 2 <= F_LDS, "residual slice must fit beside the staging area");
   const E* __restrict__ resg = reinterpret_cast<const E*>(a.res);
-  const uint32_t resvoff = (uint32_t)(((size_t)c.prow * a.Cout_p + (size_t)c.pchunk * 8) * 2);
+  const uint32_t resvoff = (uint32_t)(((size_t)e_prow * a.Cout_p + (size_t)e_pchunk * 8) * 2);
   auto issue_res = [&](int q) {
     if constexpr (RES_LDS) {
 #pragma unroll
@@ -434,7 +542,7 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
   __syncthreads();            // the next tile's LDS-DMA overwrites the staging / reduction area
 }
 
-template <typename E, bool BN, bool RESX, bool STAMP = false, bool GLU = false>
+template <typename E, bool BN, bool RESX, int DIAG = 0, bool GLU = false>
 __global__ __launch_bounds__(256, 2) void conv3_flat_kernel(const sda_conv_args a, const int n_units, const int units_per_wg,
                                                             const int runs_per_co, const long total_rows, const int Tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -475,11 +583,17 @@ __global__ __launch_bounds__(256, 2) void conv3_flat_kernel(const sda_conv_args 
   // (blockIdx / 8) 0..31 and 32..63 of an XCD are the co-resident pairs (verified with tools/flat_timeline.py; not
   // guaranteed, it only matters for speed).  With flag 1024 the second of a pair takes its 128-row tile(s) FIRST, the
   // first one LAST, so that their epilogues fall at different times; measured: no gain, default off.
-  const bool small_first = (((blockIdx.x >> 3) >> 5) & 1) && (a.flags & 1024);       // flag 1024 (diagnostic): stagger the tile order (measured: no gain)
-  // (diagnostic) a static priority for one workgroup of each co-resident pair
-  if (((blockIdx.x >> 3) >> 5) & 1) {
-    if (a.flags & 64) __builtin_amdgcn_s_setprio(2);         // flag 64 (diagnostic): static priority for one of the pair (measured: no gain)
-  }
+  // flags 1024 / 2048 (diagnostic): a different tile order (128-row tile first) for the second workgroup of every CU / for
+  // every other CU — spreads the epilogues (HBM bursts) over more distinct moments
+  const bool small_first = ((((blockIdx.x >> 3) >> 5) & 1) && (a.flags & 1024)) || (((blockIdx.x >> 3) & 1) && (a.flags & 2048));
+  // The two workgroups of a CU share each SIMD's matrix pipe and issue slots, arbitrated by priority, then AGE: at equal
+  // priority the first-dispatched one wins every time — it runs its three units in 42 us and the second one in 54 us, the
+  // last 11 us alone on the CU at a single workgroup's (poor) rate (tools/flat_timeline.py).  So the second
+  // workgroup of each pair holds priority 1 for its FIRST tile and drops it afterwards: each is the winner for about half
+  // of its work and both finish together.  Which workgroups share a CU is the dispatcher's business (observed: blocks i and
+  // i + 8 * 32 of an XCD) — a wrong guess costs speed only.
+  const bool younger = (((blockIdx.x >> 3) >> 5) & 1) && !(a.flags & 64);              // flag 64 (diagnostic): no priority hand-over
+  if (younger) __builtin_amdgcn_s_setprio(1);
   int n = u_end - u;
   if (n <= 0) return;
   // tile plan: `pairs` 256-row tiles and `lead` + `tail` 128-row tiles around them
@@ -505,14 +619,14 @@ __global__ __launch_bounds__(256, 2) void conv3_flat_kernel(const sda_conv_args 
     dbg[3] = (unsigned long long)u;
   }
   stamp();
-  if constexpr (STAMP) {       // only 256-row tiles are stamped; sums land behind the wall-clock stamps of this workgroup
+  if constexpr (DIAG == 1) {       // only 256-row tiles are stamped; sums land behind the wall-clock stamps of this workgroup
     if (dbg && c.tid == 0) { for (int i = 0; i < 5; ++i) dbg[16 + i] = 0; }
-    for (int p = 0; p < pairs; ++p, u += 2) { flat_tile<E, BN, 8, RESX, true>(a, smem, c, (long)u * F_UNIT, u, dbg ? dbg + 16 : nullptr); stamp(); }
+    for (int p = 0; p < pairs; ++p, u += 2) { flat_tile<E, BN, 8, RESX, 1>(a, smem, c, (long)u * F_UNIT, u, dbg ? dbg + 16 : nullptr); stamp(); }
     return;
   }
-  if (lead) { flat_tile<E, BN, 4, RESX, false, GLU>(a, smem, c, (long)u * F_UNIT, u); ++u; stamp(); }
-  for (int p = 0; p < pairs; ++p, u += 2) { flat_tile<E, BN, 8, RESX, false, GLU>(a, smem, c, (long)u * F_UNIT, u); stamp(); }
-  if (tail) { flat_tile<E, BN, 4, RESX, false, GLU>(a, smem, c, (long)u * F_UNIT, u); stamp(); }
+  if (lead) { flat_tile<E, BN, 4, RESX, (DIAG > 1 ? DIAG : 0), GLU>(a, smem, c, (long)u * F_UNIT, u); ++u; stamp(); __builtin_amdgcn_s_setprio(0); }
+  for (int p = 0; p < pairs; ++p, u += 2) { flat_tile<E, BN, 8, RESX, (DIAG > 1 ? DIAG : 0), GLU>(a, smem, c, (long)u * F_UNIT, u); stamp(); __builtin_amdgcn_s_setprio(0); }
+  if (tail) { flat_tile<E, BN, 4, RESX, (DIAG > 1 ? DIAG : 0), GLU>(a, smem, c, (long)u * F_UNIT, u); stamp(); }
 }
 
 struct FlatPlan { int n_units, units_per_wg, runs_per_co, grid; };
@@ -535,16 +649,15 @@ FlatPlan flat_plan(const sda_conv_args& a) {
   const long slots = ((a.flags & SDA_CONV_ONE_PER_CU) ? 1L : 2L) * cus;
   p.units_per_wg = (int)(((long)p.n_units * n_co + slots - 1) / slots);
   if (p.units_per_wg < 1) p.units_per_wg = 1;
-  if (a.flags & 2048) p.units_per_wg = 2;                        // diagnostic: one 256-row tile per workgroup, several rounds
   p.runs_per_co = (p.n_units + p.units_per_wg - 1) / p.units_per_wg;
   p.grid = p.runs_per_co * n_co;
   return p;
 }
 
-template <typename E, bool BN, bool RESX, bool STAMP = false, bool GLU = false>
+template <typename E, bool BN, bool RESX, int DIAG = 0, bool GLU = false>
 int launch_flat(const sda_conv_args& a, hipStream_t st) {
   static bool attr_done = false;
-  auto kern = conv3_flat_kernel<E, BN, RESX, STAMP, GLU>;
+  auto kern = conv3_flat_kernel<E, BN, RESX, DIAG, GLU>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS) != hipSuccess) {
       set_error("conv3_flat: cannot reserve %d bytes of LDS", F_LDS);
@@ -566,20 +679,22 @@ bool conv3_flat_supports(const sda_conv_args& a) {
   const bool glu = a.flags & SDA_EPI_GLU;
   if (glu ? (a.res || a.stats || a.bn_x) : a.y_pre != nullptr) return false;
   return a.KS == 3 && a.Cout_p % F_CO == 0 && !a.widx && a.ksplit == 1 && (!a.partial || (a.flags & 32)) && !(a.flags & SDA_EPI_GELU) &&
-         a.y && a.x_row0 == PAD && a.x_sample_rows == rows_tp(a.T) && (!a.bn_x || (a.bn_coef && a.stats)) &&
+         a.y && a.x_row0 == PAD && a.x_pitch == a.w_pitch && a.x_sample_rows == rows_tp(a.T) && (!a.bn_x || (a.bn_coef && a.stats)) &&
 
          a.x_rows_limit >= (long)a.B * rows_tp(a.T) + 3 * PAD && a.x_rows_limit < (1L << 31) && a.w_rows_limit >= a.Cout_p &&
          a.Cin_p / (ROW_B / (a.dtype == SDA_F32 ? 4 : 2)) >= 1;
 }
 
 template <typename E> static int launch_flat_e(const sda_conv_args& a, hipStream_t st) {
-  if (a.flags & SDA_EPI_GLU) return launch_flat<E, false, false, false, true>(a, st);
+  if (a.flags & SDA_EPI_GLU) return launch_flat<E, false, false, 0, true>(a, st);
   if (a.bn_x) return a.res ? launch_flat<E, true, true>(a, st) : launch_flat<E, true, false>(a, st);
   return a.res ? launch_flat<E, false, true>(a, st) : launch_flat<E, false, false>(a, st);
 }
 
 int launch_conv3_flat(const sda_conv_args& a, hipStream_t st) {
-  if ((a.flags & 128) && (a.flags & 32) && a.dtype == SDA_BF16 && !a.bn_x && !a.res) return launch_flat<uint16_t, false, false, true>(a, st);   // diagnostic
+  if ((a.flags & 128) && (a.flags & 32) && a.dtype == SDA_BF16 && !a.bn_x && !a.res) return launch_flat<uint16_t, false, false, 1>(a, st);   // diagnostic
+  if ((a.flags & 24) && a.dtype == SDA_BF16 && !a.bn_x && !a.res && !(a.flags & SDA_EPI_GLU))                                        // diagnostic (garbage results)
+    return (a.flags & 8) ? launch_flat<uint16_t, false, false, 3>(a, st) : launch_flat<uint16_t, false, false, 2>(a, st);
   if (a.dtype == SDA_F32) return launch_flat_e<float>(a, st);
   if (a.dtype == SDA_F16) return launch_flat_e<half_t>(a, st);
   return launch_flat_e<uint16_t>(a, st);

@@ -256,17 +256,16 @@ __device__ inline float wave_max(float v) {
 // first read — which serialises the copy of slab s+1 against the MFMAs of slab s.  The asm form is invisible
 // to that bookkeeping: completion is enforced by OUR counted s_waitcnt vmcnt(N) + barrier.
 //   gsrc: this lane's 16 source bytes; lds_dst: wave-uniform LDS byte address; lane l lands at lds_dst + 16*l.
+// M0 (the LDS destination base) is written in the statement that reads it and NOT saved: hipcc keeps no value of its own
+// in M0 across statements in these kernels (tools/check_dma_hazard.py also lists compiler-generated uses of M0, there are none).
 __device__ inline void lds_dma16(const void* gsrc, uint32_t lds_dst_in) {
   const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_in);   // wave-uniform by contract
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 // The same with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset: when
 // the piece's row is wave-uniform all per-piece arithmetic is scalar and ONE offset register serves every piece.
-// (s_nop 4: a base that was just produced by v_readfirstlane needs 5 wait states before a VMEM instruction reads it.)
+// (s_nop 4: a base that was just produced by v_readfirstlane / v_readlane needs 5 wait states before a VMEM instruction
+// reads it, and hipcc pads nothing inside an asm statement.)
 __device__ inline void lds_dma16_sv(const void* sbase_in, uint32_t voff, uint32_t lds_dst_in) {
   const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_in);
   // the base IS wave-uniform by construction; where hipcc cannot prove it, make it provable (folds away where it can)
@@ -275,11 +274,7 @@ __device__ inline void lds_dma16_sv(const void* sbase_in, uint32_t voff, uint32_
   const uint32_t sb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sb64 >> 32));
   const uint32_t sb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sb64);
   const void* sbase = (const void*)(uintptr_t)(((uint64_t)sb_hi << 32) | (uint64_t)sb_lo);
-  uint32_t keep;
-  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory");
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 __device__ inline uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const void*)p);

@@ -31,12 +31,16 @@ def main():
                              ("neither", dict(flags=768)), ("pair_full", dict(bias=bias, res=res, stats=stats, flags=8192)),
                              ("flat", dict(bias=bias, res=res, stats=stats, flags=16384)), ("flat_plain", dict(flags=16384)),
                              ("flat_noepi", dict(flags=16384 | 256)),
-                             ("flat_nostag", dict(bias=bias, res=res, stats=stats, flags=16384 | 1024)),
-                             ("flat_nostag_noepi", dict(flags=16384 | 1024 | 256)),
-                             ("flat_rounds", dict(bias=bias, res=res, stats=stats, flags=16384 | 2048 | 1024)),
-                             ("flat_rounds_noepi", dict(flags=16384 | 2048 | 1024 | 256)),
-                             ("flat_nostag_noprio", dict(bias=bias, res=res, stats=stats, flags=16384 | 1024 | 64)),
-                             ("flat_nostag_noepi_noprio", dict(flags=16384 | 1024 | 256 | 64))]:
+
+                             ("flat_noho", dict(bias=bias, res=res, stats=stats, flags=16384 | 64)),       # 64: no priority hand-over
+                             ("flat_noepi_noho", dict(flags=16384 | 256 | 64)),
+                             ("flat_1024", dict(bias=bias, res=res, stats=stats, flags=16384 | 1024)),
+                             ("flat_2048", dict(bias=bias, res=res, stats=stats, flags=16384 | 2048)),
+                             ("flat_3072", dict(bias=bias, res=res, stats=stats, flags=16384 | 3072)),
+                             ("flat_1024_noho", dict(bias=bias, res=res, stats=stats, flags=16384 | 1024 | 64)),
+                             ("flat_2048_noho", dict(bias=bias, res=res, stats=stats, flags=16384 | 2048 | 64)),
+                             ("flat_noepi_nodma", dict(flags=16384 | 256 | 16)),       # diagnostic builds: no LDS-DMA in the K loop
+                             ("flat_noepi_nodma_nolds", dict(flags=16384 | 256 | 8))]:  # ... and no fragment reads either (MFMA only)
                 if KS != 3 and name.startswith("flat"):
                     continue
                 us = timeit(lambda: ops.conv_gemm(x, wp, y, B=B, T=T, KS=KS, dil=dil, **kw))

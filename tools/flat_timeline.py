@@ -44,6 +44,8 @@ def main():
     run(16384 | 32 | extra, True)
     torch.cuda.synchronize()
     d = dbg.cpu().numpy()
+    if os.environ.get("FLAT_TIMELINE_SAVE"):
+        np.save(os.environ["FLAT_TIMELINE_SAVE"], d)
     d = d[d[:, 4] != 0]
     t0 = d[:, 4].min()
     hw, xcc = d[:, 0], d[:, 1] & 0xf
@@ -61,6 +63,17 @@ def main():
     for k in range(int(nst.max())):
         tk = (d[nst > k, 4 + k] - t0) / 100.0
         print(f"stamp {k}: n={len(tk)} min {tk.min():.1f} us  median {np.median(tk):.1f}  max {tk.max():.1f}")
+    # spread: when workgroups start / end, how long they live, by XCD
+    start = (d[:, 4] - t0) / 100.0
+    end = (d[rows, 4 + last] - t0) / 100.0
+    life = end - start
+    q = lambda v: "  ".join(f"{np.percentile(v, p_):6.1f}" for p_ in (0, 10, 50, 90, 100))
+    print(f"start  us (min p10 p50 p90 max): {q(start)}")
+    print(f"end    us (min p10 p50 p90 max): {q(end)}")
+    print(f"life   us (min p10 p50 p90 max): {q(life)}")
+    for xc in np.unique(xcc):
+        sel = xcc == xc
+        print(f"   xcd {xc}: {sel.sum():3d} workgroups  life p50 {np.median(life[sel]):6.1f}  max {life[sel].max():6.1f}  end max {end[sel].max():6.1f}  clock {np.median(ghz[sel]):.3f}")
     # per-plan durations
     plans = d[:, 2]
     for pl in np.unique(plans):
