@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 2   /* 2: sda_conv_args gained glu_out / glu_gate, sda_pack_desc gained glu_tile, flag 16384 = SDA_CONV_FLAT_TILES */
+#define SDA_ABI_VERSION 3   /* 2: sda_conv_args gained glu_out / glu_gate, sda_pack_desc gained glu_tile, flag 16384 = SDA_CONV_FLAT_TILES;
+                               (still 2, should have been bumped: sda_wgrad_args.acc_scale, new arguments of sda_bn_finalize,
+                               sda_clip_logits_stats and sda_clip_grad, new entries sda_clip_dz / sda_param_gemm / sda_copy3d)
+                               3: sda_wgrad_args.flags (SDA_WGRAD_FLAT_ROWS), sda_stream_create_cumask / sda_stream_destroy,
+                               conv3_flat takes x_pitch == w_pitch only */
 #define SDA_ROW_PAD 16
 #define SDA_CH_ALIGN 64
 
@@ -222,6 +226,10 @@ int sda_colsum(const void* x, float* out, float* scratch /* sda_reduce_scratch_f
  * Samples are visited through `perm` (device int32 [B]); segment s covers perm[seg_start[s]..seg_start[s+1]).
  * Output fp32 slabs [nseg][KS][Cout_p][Cin_p].  With out_e != NULL (KS must be 1, nseg 1) the result is
  * written as `dtype` rows instead:  out_e[co][ci] = out_scale * (acc_scale[co] * acc - rscale[co] * sub[co][ci])   (loss backward dZ). */
+/* sda_wgrad_args.flags */
+enum { SDA_WGRAD_FLAT_ROWS = 1  /* perm == NULL and dy is a row-layout buffer whose rows between samples (the SDA_ROW_PAD rows in
+                                   front of every sample) are zero: a segment is contracted as ONE run of rows, pad rows included
+                                   (they contribute nothing), in whole K-chunks — no partial chunk per sample */ };
 typedef struct sda_wgrad_args {
   const void* dy;       /* RL [rows][dy_pitch] */
   const void* x;        /* RL [rows][x_pitch] */
@@ -240,6 +248,7 @@ typedef struct sda_wgrad_args {
   int co_valid;           /* rows of out_e to write (out_e mode) */
   int dtype;
   const float* acc_scale; /* optional [Cout]: multiplies the fp32 accumulator of typed-output row co before `sub` is taken off */
+  int flags;              /* SDA_WGRAD_FLAT_ROWS */
 } sda_wgrad_args;
 int sda_wgrad_gemm(const sda_wgrad_args* a, void* stream);
 /* dst[i] = sum_s src[s][i] in fixed order */
@@ -295,6 +304,13 @@ int sda_clip_dz(const void* G, long g_pitch, const void* Y, const void* Z, void*
 /* cnt[i] = #{local j : logits[i][j] beats diag[i]} (ties: lower global index wins) — Classifier ranks */
 int sda_clip_ranks(const float* logits, const float* diag, int32_t* cnt, int Bm, int Bn, int col0, void* stream);
 int sda_device_count(void);
+/* CU partitions (diagnostic / scheduling experiments): a HIP stream whose kernels run only on the CUs set in `mask` (bit i of
+ * word i / 32 = CU i in the runtime's numbering; hipExtStreamCreateWithCUMask), and the CU count persistent grids launched
+ * from THIS thread should size themselves for (0 = the device's; returns the previous limit).  The stream is created in
+ * the calling process and destroyed with sda_stream_destroy. */
+int sda_stream_create_cumask(const uint32_t* mask, int nwords, void** stream);
+int sda_stream_destroy(void* stream);
+int sda_set_cu_limit(int cus);
 
 /* Batched fp32 matrix product on parameter-sized operands with arbitrary element strides (exact-fp32 MFMA):
  *     C[b][i][j] = sum_{k < K} A[b][i][k] * B[b][k][j],    i < M, j < N, b < batch

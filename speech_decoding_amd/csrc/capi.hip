@@ -25,7 +25,51 @@ int check_launch(const char* what) {
   return 0;
 }
 
+static int current_device() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}
+
+bool first_use_on_device(unsigned long long& done) {
+  const unsigned long long bit = 1ull << (current_device() & 63);
+  if (done & bit) return false;
+  done |= bit;
+  return true;
+}
+
+static thread_local int g_cu_limit = 0;
+
+int launch_cus() {
+  static int cus[64] = {0};
+  const int dev = current_device() & 63;
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  return (g_cu_limit > 0 && g_cu_limit < cus[dev]) ? g_cu_limit : cus[dev];
+}
+
 }  // namespace sda
+
+extern "C" int sda_set_cu_limit(int cus) {
+  const int old = sda::g_cu_limit;
+  sda::g_cu_limit = cus > 0 ? cus : 0;
+  return old;
+}
+extern "C" int sda_stream_create_cumask(const uint32_t* mask, int nwords, void** stream) {
+  if (!mask || nwords < 1 || !stream) { sda::set_error("stream_create_cumask: bad arguments"); return -1; }
+  hipStream_t st = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask);
+  if (e != hipSuccess) { sda::set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return -2; }
+  *stream = (void*)st;
+  return 0;
+}
+extern "C" int sda_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) { sda::set_error("hipStreamDestroy: %s", hipGetErrorString(e)); return -2; }
+  return 0;
+}
 
 extern "C" int sda_abi_version(void) { return SDA_ABI_VERSION; }
 extern "C" const char* sda_last_error(void) { return sda::g_err; }

@@ -636,14 +636,7 @@ FlatPlan flat_plan(const sda_conv_args& a) {
   const long total_rows = (long)a.B * rows_tp(a.T);
   p.n_units = (int)((total_rows + F_UNIT - 1) / F_UNIT);
   const int n_co = a.Cout_p / F_CO;
-  int dev = 0, cus = 256;
-  static int cached_cus = 0;
-  if (!cached_cus) {
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached_cus = prop.multiProcessorCount;
-    else cached_cus = 256;
-  }
-  cus = cached_cus;
+  const int cus = launch_cus();
   // two workgroups per CU; one with SDA_CONV_ONE_PER_CU (the caller wants the other half of every CU's LDS for a kernel on
   // another stream: in backward the weight-gradient GEMMs run beside the data-gradient convs)
   const long slots = ((a.flags & SDA_CONV_ONE_PER_CU) ? 1L : 2L) * cus;
@@ -656,14 +649,13 @@ FlatPlan flat_plan(const sda_conv_args& a) {
 
 template <typename E, bool BN, bool RESX, int DIAG = 0, bool GLU = false>
 int launch_flat(const sda_conv_args& a, hipStream_t st) {
-  static bool attr_done = false;
+  static unsigned long long attr_done = 0;        // per device
   auto kern = conv3_flat_kernel<E, BN, RESX, DIAG, GLU>;
-  if (!attr_done) {
+  if (first_use_on_device(attr_done)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS) != hipSuccess) {
       set_error("conv3_flat: cannot reserve %d bytes of LDS", F_LDS);
       return -3;
     }
-    attr_done = true;
   }
   const FlatPlan p = flat_plan(a);
   hipLaunchKernelGGL(kern, dim3((unsigned)p.grid), dim3(256), F_LDS, st, a, p.n_units, p.units_per_wg, p.runs_per_co,

@@ -558,15 +558,14 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
 template <typename E, int TILE_CO, int KS, int NT, bool BN = false, bool SV = true>
 static int launch_conv(const sda_conv_args& a, hipStream_t st) {
   constexpr int lds = conv_lds_bytes<TILE_CO, KS, NT, SV>();
-  static bool attr_done = false;
+  static unsigned long long attr_done = 0;        // per device
   auto kern = conv_gemm_kernel<E, TILE_CO, KS, NT, BN, SV>;
-  if (!attr_done) {
+  if (first_use_on_device(attr_done)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             lds) != hipSuccess) {
       set_error("conv_gemm: cannot reserve %d bytes of LDS", lds);
       return -3;
     }
-    attr_done = true;
   }
   const int n_t = (a.T + TILE_T - 1) / TILE_T;
   const long groups = ((long)a.B * n_t + NT - 1) / NT;

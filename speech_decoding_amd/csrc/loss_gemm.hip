@@ -146,21 +146,15 @@ __global__ __launch_bounds__(256, 2) void clip_dz_kernel(const E* __restrict__ G
 template <typename E>
 int launch_dz(const void* G, long g_pitch, const void* Y, const void* Z, void* out, const float* cscale, const float* rscale,
               const float* out_scale, int Bm, int Bn, long row_elems, hipStream_t st) {
-  static bool attr_done = false;
+  static unsigned long long attr_done = 0;        // per device
   auto kern = clip_dz_kernel<E>;
-  if (!attr_done) {
+  if (first_use_on_device(attr_done)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DZ_LDS) != hipSuccess) {
       set_error("clip_dz: cannot reserve %d bytes of LDS", DZ_LDS);
       return -3;
     }
-    attr_done = true;
   }
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-  }
+  const int cus = launch_cus();
   const int ntiles = (int)(row_elems / DZ_KT);
   const int jblocks = (Bn + 255) / 256;
   int gx = 2 * cus / jblocks;                          // two workgroups per CU in all

@@ -283,5 +283,11 @@ __device__ inline uint32_t lds_addr(const void* p) {
 // host-side error plumbing (capi.hip)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// Per-DEVICE launch state (a process may drive several GPUs): `done` is a static bit mask owned by the call site; true the
+// first time the CURRENT device asks (hipFuncSetAttribute is per device).
+bool first_use_on_device(unsigned long long& done);
+// CUs a persistent grid may count on: the current device's CU count, or the limit the caller set for launches that go to
+// a CU-masked stream (sda_set_cu_limit; thread-local, 0 = none)
+int launch_cus();
 
 }  // namespace sda

@@ -51,6 +51,28 @@ template <int RB> __device__ inline uint4 tr_operand_f32(const unsigned char* im
   }
   return r;
 }
+// The same read split into a per-lane byte offset that is computed ONCE (tr_offset: everything that depends on the lane,
+// on the operand's column and on the low bits of its first row — the swizzle only looks at row bits 0..2) and the read
+// itself at `img + off` plus a compile-time row offset (a multiple of 16 rows: the swizzle does not see it): inside a
+// K loop a fragment read is then ONE address add instead of ~10 vector instructions per fragment — the MFMAs share the
+// vector issue port with them (wgrad_gemm's chunk loop had two VALU instructions per MFMA).
+template <int RB> __device__ inline uint32_t tr_offset_bf16(int row0, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int row = row0 + 4 * g + q;
+  const int colb = (col0 + 4 * p) * 2;
+  return (uint32_t)(row * RB + ((((colb >> 4) ^ chunk_xor<uint16_t, RB>(row))) << 4) + (colb & 15));
+}
+template <int RB> __device__ inline uint4 tr_read_bf16(const unsigned char* img_plus_off) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img_plus_off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img_plus_off + 16 * RB));
+  uint4 r;
+  r.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+  r.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+  r.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+  r.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+  return r;
+}
 template <typename E, int RB> struct TrOp;
 template <int RB> struct TrOp<uint16_t, RB> {
   __device__ static uint4 get(const unsigned char* img, int row0, int col0, int lane) { return tr_operand_bf16<RB>(img, row0, col0, lane); }

@@ -137,22 +137,46 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
   const int s_beg = a.seg_start ? a.seg_start[seg] : 0;
   const int s_end = a.seg_start ? a.seg_start[seg + 1] : a.B;
   const int nchunk = (a.T + KT - 1) / KT;
-  const int total = (s_end - s_beg) * nchunk;
+  // Two ways to cut a segment's rows into K-chunks of KT rows:
+  //   per sample (the general form; `perm` may reorder samples): chunk it = (sample it / nchunk, rows [ch * KT, ch * KT + KT) of it);
+  //     a sample's last chunk is partial (T = 360: 5 x 64 + 40) and takes the per-lane staging path;
+  //   flat (SDA_WGRAD_FLAT_ROWS, consecutive samples): the segment is ONE run of rows — the valid rows of its samples and the
+  //     layout's pad rows between them, which are zero in dy and therefore contribute nothing (they are the zero padding a
+  //     "same" convolution reads, models.py:128-150) — cut into KT-row chunks regardless of sample boundaries: only the
+  //     segment's very last chunk is partial, every other one takes the scalar-base staging path, and 376 / 360 rows are
+  //     contracted per sample instead of 384 / 360.
+  const bool flat = (a.flags & SDA_WGRAD_FLAT_ROWS) && !a.perm && s_end > s_beg;
+  const long seg_r0 = a.row0 + (long)s_beg * a.sample_rows;                               // first row of the run
+  const long seg_r1 = a.row0 + (long)(s_end - 1) * a.sample_rows + a.T;                   // one past its last valid row
+  const int total = flat ? (int)((seg_r1 - seg_r0 + KT - 1) / KT) : (s_end - s_beg) * nchunk;
 
-  // one K-chunk = KT rows of one sample.  DMA pieces are 1 KB, lane-linear in LDS; each lane derives the
-  // (row, chunk) its 16 bytes belong to and fetches the swizzle-matched source chunk.  dy rows at t >= T
-  // come from a guaranteed-zero row (they must not contribute); x rows are merely clamped into the buffer.
+  // one K-chunk = KT rows.  DMA pieces are 1 KB, lane-linear in LDS; each lane derives the (row, chunk) its 16 bytes
+  // belong to and fetches the swizzle-matched source chunk.  dy rows past the chunk's valid ones come from a
+  // guaranteed-zero row (they must not contribute); x rows are merely clamped into the buffer.
   // (the sample index is read from `perm` once per SAMPLE: a global load in the chunk loop is waited for with vmcnt(0))
-  int staged_si = -1, staged_b = 0;
-  auto stage = [&](int it, int buf) {
-    const int si = it / nchunk, ch = it - si * nchunk;
-    if (si != staged_si) {
-      staged_si = si;
-      staged_b = a.perm ? __builtin_amdgcn_readfirstlane(a.perm[s_beg + si]) : (s_beg + si);
+  // Chunks are visited in order, so (sample, chunk-in-sample) advance incrementally: no division in the loop.
+  int cur_si = 0, cur_ch = -1, cur_it = -1, staged_b = 0;
+  long c_row = 0;                 // first dy row of the chunk described last
+  int c_valid = 0;                // its number of valid rows (<= KT)
+  auto describe = [&](int it) {   // it == cur_it + 1 (or cur_it: idempotent)
+    if (it == cur_it) return;
+    cur_it = it;
+    if (flat) {
+      c_row = seg_r0 + (long)it * KT;
+      const long left = seg_r1 - c_row;
+      c_valid = left < KT ? (int)left : KT;
+      return;
     }
-    const int b = staged_b;
-    const long srow = a.row0 + (long)b * a.sample_rows;
-    const int t0 = ch * KT;
+    if (++cur_ch == nchunk || it == 0) {
+      if (it != 0) { cur_ch = 0; ++cur_si; }
+      staged_b = a.perm ? __builtin_amdgcn_readfirstlane(a.perm[s_beg + cur_si]) : (s_beg + cur_si);
+    }
+    const int t0 = cur_ch * KT;
+    c_row = a.row0 + (long)staged_b * a.sample_rows + t0;
+    c_valid = a.T - t0 < KT ? a.T - t0 : KT;
+  };
+  auto stage = [&](int it, int buf) {
+    describe(it);
     unsigned char* dys = smem + buf * G::STAGE;
     unsigned char* xs = dys + G::DY_BYTES;
 #pragma unroll
@@ -162,7 +186,7 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
         const int byte = p * 1024 + lane * 16;
         const int r = byte / G::RB_M;
         const int c = ((byte - r * G::RB_M) >> 4) ^ chunk_xor<E, G::RB_M>(r);
-        const long row = (t0 + r < a.T) ? (srow + t0 + r) : a.dy_zero_row;
+        const long row = (r < c_valid) ? (c_row + r) : a.dy_zero_row;
         lds_dma16(dyg + (size_t)row * a.dy_pitch + co0 + c * PER16,
                   __builtin_amdgcn_readfirstlane(lds_addr(dys + p * 1024)));
       }
@@ -171,7 +195,7 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
       const int byte = p * 1024 + lane * 16;
       const int r = byte / G::RB_N;
       const int c = ((byte - r * G::RB_N) >> 4) ^ chunk_xor<E, G::RB_N>(r);
-      long row = srow + t0 - halo + r;
+      long row = c_row - halo + r;
       row = row < 0 ? 0 : (row >= a.rows_limit ? a.rows_limit - 1 : row);
       lds_dma16(xg + (size_t)row * a.x_pitch + ci0 + c * PER16,
                   __builtin_amdgcn_readfirstlane(lds_addr(xs + p * 1024)));
@@ -207,16 +231,10 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
   uint32_t nxt_off = 0;
   // chunk `it` -> is it a fast one?  sets the bases; the slow path stages it at once
   auto prepare = [&](int it, int buf) -> bool {
-    const int si = it / nchunk, ch = it - si * nchunk;
-    if (si != staged_si) {
-      staged_si = si;
-      staged_b = a.perm ? __builtin_amdgcn_readfirstlane(a.perm[s_beg + si]) : (s_beg + si);
-    }
-    const long srow = a.row0 + (long)staged_b * a.sample_rows;
-    const int t0 = ch * KT;
-    const long xrow0 = srow + t0 - halo;
-    if (t0 + KT <= a.T && xrow0 >= 0 && xrow0 + KT + 2 * halo <= a.rows_limit) {
-      dy_base = dyg + (size_t)(srow + t0) * a.dy_pitch + co0;
+    describe(it);
+    const long xrow0 = c_row - halo;
+    if (c_valid == KT && xrow0 >= 0 && xrow0 + KT + 2 * halo <= a.rows_limit) {
+      dy_base = dyg + (size_t)c_row * a.dy_pitch + co0;
       x_base = xg + (size_t)xrow0 * a.x_pitch + ci0;
       nxt_off = (uint32_t)(buf * G::STAGE);
       return true;
@@ -238,6 +256,18 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
   constexpr int NGRP = (KT / KSTEP) * KS;      // MFMA groups per chunk
   constexpr int PER_GRP = (NPW + NGRP - 1) / NGRP;
 
+  // 16-bit types: per-lane offsets of every transposed fragment read of a stage, computed once (tr_operand.h); a read of
+  // K-step kk is then `stage base + offset` plus the immediate kk * KSTEP rows
+  constexpr bool FASTTR = sizeof(E) == 2;
+  uint32_t a_off[FASTTR ? MREP : 1], b_off[FASTTR ? KS : 1][FASTTR ? NREP : 1];
+  if constexpr (FASTTR) {
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) a_off[m] = tr_offset_bf16<G::RB_M>(0, wave_m * (TILE_M / 2) + m * 16, lane);
+#pragma unroll
+    for (int tap = 0; tap < KS; ++tap)
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) b_off[tap][n] = G::DY_BYTES + tr_offset_bf16<G::RB_N>(tap * a.dil, wave_n * (TN / 2) + n * 16, lane);
+  }
   static_assert(NS == 2, "the chunk loop below is written for two LDS stages");
   if (0 < total) stage(0, 0);
   int cur = 0;
@@ -252,14 +282,18 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
       constexpr int kk = decltype(kc)::value;
       uint4 af[MREP];
 #pragma unroll
-      for (int m = 0; m < MREP; ++m)
-        af[m] = TrOp<E, G::RB_M>::get(dys, kk * KSTEP, wave_m * (TILE_M / 2) + m * 16, lane);
+      for (int m = 0; m < MREP; ++m) {
+        if constexpr (FASTTR) af[m] = tr_read_bf16<G::RB_M>(dys + a_off[m] + kk * KSTEP * G::RB_M);
+        else af[m] = TrOp<E, G::RB_M>::get(dys, kk * KSTEP, wave_m * (TILE_M / 2) + m * 16, lane);
+      }
       wg_static_for<0, KS>([&](auto tc) {
         constexpr int tap = decltype(tc)::value;
         uint4 bf[NREP];
 #pragma unroll
-        for (int n = 0; n < NREP; ++n)
-          bf[n] = TrOp<E, G::RB_N>::get(xs, kk * KSTEP + tap * a.dil, wave_n * (TN / 2) + n * 16, lane);
+        for (int n = 0; n < NREP; ++n) {
+          if constexpr (FASTTR) bf[n] = tr_read_bf16<G::RB_N>(dys + b_off[tap][n] + kk * KSTEP * G::RB_N);
+          else bf[n] = TrOp<E, G::RB_N>::get(xs, kk * KSTEP + tap * a.dil, wave_n * (TN / 2) + n * 16, lane);
+        }
 #pragma unroll
         for (int m = 0; m < MREP; ++m)
 #pragma unroll
@@ -327,15 +361,14 @@ static int launch_wgrad(const sda_wgrad_args& a, hipStream_t st) {
   // the fp32 staging of the typed epilogue only where there is one: a slab-output launch that asks for less LDS leaves
   // room on the CU for the other stream's workgroups
   const int lds = a.out_e ? lds_max : NS * WG_::STAGE;
-  static bool attr_done = false;
+  static unsigned long long attr_done = 0;        // per device
   auto kern = wgrad_gemm_kernel<E, TILE_M, KS, TN, KM, NS>;
-  if (!attr_done) {
+  if (first_use_on_device(attr_done)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             lds_max) != hipSuccess) {
       set_error("wgrad_gemm: cannot reserve %d bytes of LDS", lds_max);
       return -3;
     }
-    attr_done = true;
   }
   const long grid = (long)(a.Cin_p / TN) * (a.Cout_p / TILE_M) * a.nseg;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);

@@ -88,6 +88,7 @@ class EncoderEngine:
         self.wgrad_target_wgs = 256          # workgroups per weight-gradient launch (split over sample segments)
         # weight-gradient chains (wgrad_gemm -> reduce_slabs -> unpack) depend only on dy and a saved
         # activation, never on each other or on the data-gradient chain: run them on a second HIP stream
+        self.wgrad_flat_rows = True          # shared-weight gradients contract a segment's rows as one run (pad rows of dy are zero)
         self.wgrad_side_stream = True
         self.side_stream_priority = 0        # HIP stream priority of the weight-gradient / packing stream
         self.probe = None                    # diagnostics (tools/stream_waits.py): a list collects (label, event, event) around
@@ -511,7 +512,7 @@ class EncoderEngine:
 
             def chain():
                 slabs = ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=perm, seg_start=seg, nseg=nseg,
-                                       alg_dims=(Cin, Cout))
+                                       alg_dims=(Cin, Cout), flat_rows=self.wgrad_flat_rows)
                 return ops.reduce_unpack_wgrad(slabs, Cout, Cin, KS, **glu)
             return on_side(chain)
 
@@ -576,9 +577,10 @@ class EncoderEngine:
         flush(["f2w", "f2b", "f1w", "f1b"])
 
         # ---- ConvBlocks, last to first
-        null_bias = self._const.get(("null_bias", str(dev)))      # (never written: handed out as the gradient of biases that have none)
-        if null_bias is None:
-            null_bias = self._const[("null_bias", str(dev))] = torch.zeros((10, d.D2), dtype=torch.float32, device=dev)
+        # the gradient of the ten biases that feed a training-mode BatchNorm (identically zero): rows of ONE fresh zero buffer
+        # per backward — autograd hands these views to the parameters' .grad, so a buffer kept across steps would alias
+        # engine-owned memory into .grad (an in-place clip with a non-finite factor would poison every later step)
+        null_bias = torch.zeros((10, d.D2), dtype=torch.float32, device=dev) if ctx.training else None
         flip = 0
         for k in range(4, -1, -1):
             cin, cin_p = (d.D1, d.D1p) if k == 0 else (d.D2, d.D2p)

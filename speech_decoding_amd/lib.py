@@ -11,12 +11,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdamd.so")
 
-ABI_VERSION = 2          # SDA_ABI_VERSION of include/sd_amd.h this binding was written against
+ABI_VERSION = 3          # SDA_ABI_VERSION of include/sd_amd.h this binding was written against
 F32, BF16, F16 = 0, 1, 2
 ROW_PAD = 16
 CH_ALIGN = 64
 EPI_GELU, EPI_GLU, EPI_GLU_BWD = 1, 2, 4
 CONV_SINGLE_TILE, CONV_PAIR_TILES, CONV_FLAT_TILES, CONV_ONE_PER_CU = 4096, 8192, 16384, 32768
+WGRAD_FLAT_ROWS = 1
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
@@ -34,7 +35,7 @@ class WgradArgs(C.Structure):
                 ("seg_start", vp),
                 ("nseg", i32), ("B", i32), ("T", i32), ("Cout_p", i32), ("Cin_p", i32), ("KS", i32), ("dil", i32),
                 ("dy_pitch", i64), ("x_pitch", i64), ("out_pitch", i64), ("row0", i64), ("sample_rows", i64),
-                ("rows_limit", i64), ("dy_zero_row", i64), ("co_valid", i32), ("dtype", i32), ("acc_scale", vp)]
+                ("rows_limit", i64), ("dy_zero_row", i64), ("co_valid", i32), ("dtype", i32), ("acc_scale", vp), ("flags", i32)]
 
 
 class PackDesc(C.Structure):
@@ -59,6 +60,9 @@ SIGNATURES = {
     "sda_rows_alloc": (i64, [i32, i32]),
     "sda_pad_channels": (i32, [i32]),
     "sda_device_count": (i32, []),
+    "sda_stream_create_cumask": (i32, [vp, i32, vp]),
+    "sda_stream_destroy": (i32, [vp]),
+    "sda_set_cu_limit": (i32, [i32]),
     "sda_upload_words": (i32, [vp, vp, i64, vp]),
     "sda_pack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sda_pack_rows_ones": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -536,9 +536,12 @@ def colsum(x, B, T, scratch):
     return out
 
 
-def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1, alg_dims=None):
+def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1, alg_dims=None, flat_rows=False):
     """fp32 slabs (nseg, KS, Cout_p, Cin_p) of dy^T x over the RL rows of the samples in each segment.
-    alg_dims = (Cin, Cout) unpadded, only used to count algorithmic FLOPs when the timer is on."""
+    alg_dims = (Cin, Cout) unpadded, only used to count algorithmic FLOPs when the timer is on.
+    flat_rows: the caller guarantees that dy's pad rows (the 16 rows in front of every sample) are zero — true for every
+    row-layout buffer the kernels of this library write (they only ever write valid rows of zero-initialised buffers) —
+    so a segment of consecutive samples is contracted as one run of rows in whole K-chunks (SDA_WGRAD_FLAT_ROWS)."""
     a = L.WgradArgs()
     g = torch.empty((nseg, KS, dy.shape[1], x.shape[1]), dtype=torch.float32, device=x.device)
     a.dy, a.x, a.g, a.out_e, a.sub, a.rscale, a.out_scale = _p(dy), _p(x), _p(g), None, None, None, None
@@ -547,6 +550,7 @@ def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1, alg_d
     a.dy_pitch, a.x_pitch, a.out_pitch = dy.shape[1], x.shape[1], 0
     a.row0, a.sample_rows, a.rows_limit, a.dy_zero_row = L.ROW_PAD, L.rows_tp(T), x.shape[0], 0
     a.co_valid, a.dtype, a.acc_scale = 0, dt_code(x.dtype), None
+    a.flags = L.WGRAD_FLAT_ROWS if (flat_rows and perm is None) else 0
     if nseg > 1 and seg_start is None:
         raise L.SdaError("wgrad_gemm: nseg > 1 needs seg_start")
     if TIMER is not None and "wgrad_gemm" in TIMER.families:   # events go on the CURRENT stream (the side stream in backward)

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     L = lib.load()
     header = open(os.path.join(ROOT, "include", "sd_amd.h")).read()
     declared = int(re.search(r"#define\s+SDA_ABI_VERSION\s+(\d+)", header).group(1))
-    assert L.sda_abi_version() == declared == lib.ABI_VERSION == 2
+    assert L.sda_abi_version() == declared == lib.ABI_VERSION == 3
 
 
 def test_layout_helpers_agree_with_python_mirror(lib):
@@ -57,8 +57,8 @@ def test_struct_layout_matches_c(lib, tmp_path):
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sd_amd.h"\nint main(void){\n'
                    'printf("%zu %zu %zu %zu %zu\\n", sizeof(sda_conv_args), offsetof(sda_conv_args, B), '
                    'offsetof(sda_conv_args, x_pitch), offsetof(sda_conv_args, w_rows_limit), offsetof(sda_conv_args, dtype));\n'
-                   'printf("%zu %zu %zu %zu %zu\\n", sizeof(sda_wgrad_args), offsetof(sda_wgrad_args, nseg), '
-                   'offsetof(sda_wgrad_args, dy_pitch), offsetof(sda_wgrad_args, rows_limit), offsetof(sda_wgrad_args, dtype));\n'
+                   'printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sda_wgrad_args), offsetof(sda_wgrad_args, nseg), '
+                   'offsetof(sda_wgrad_args, dy_pitch), offsetof(sda_wgrad_args, rows_limit), offsetof(sda_wgrad_args, dtype), offsetof(sda_wgrad_args, flags));\n'
                    'return 0;}\n')
     exe = tmp_path / "probe"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
@@ -67,7 +67,7 @@ def test_struct_layout_matches_c(lib, tmp_path):
     assert [int(v) for v in out[0].split()] == [ctypes.sizeof(ca), ca.B.offset, ca.x_pitch.offset,
                                                 ca.w_rows_limit.offset, ca.dtype.offset]
     assert [int(v) for v in out[1].split()] == [ctypes.sizeof(wa), wa.nseg.offset, wa.dy_pitch.offset,
-                                                wa.rows_limit.offset, wa.dtype.offset]
+                                                wa.rows_limit.offset, wa.dtype.offset, wa.flags.offset]
 
 
 def test_argument_validation_without_launch(lib):

@@ -205,3 +205,35 @@ def test_row_statistics_merge_equals_a_global_log_sum_exp():
     assert torch.allclose(lse, torch.logsumexp(logits, dim=1), rtol=0, atol=1e-12)
     assert torch.equal(diag, logits.diagonal())
     assert torch.allclose(combine_row_stats(torch.stack(stats)[:, :2]), lse)          # without the diagonal: the lse alone
+
+
+def test_loss_scaler_guards_fp16_whatever_the_scale_and_never_grows_below_its_start():
+    """amp.LossScaler: the overflow guard belongs to the DTYPE (fp16), not to the scale's value — a scale halved down to 1 (or
+    fp16_loss_scale=1) still checks for inf / NaN; growth never caps below the calibrated start (131072 at 8192 x 1000)."""
+    from speech_decoding_amd.amp import LossScaler, fp16_scale_for
+    s = LossScaler.for_dtype(torch.float16, global_batch=8192, T=1000)
+    assert s.enabled and s.scale_value == fp16_scale_for(8192, 1000) == 131072.0
+    s.growth_interval = 1
+    s.update(True)
+    assert s.scale_value == 262144.0                      # grows past 65536, never below the start
+    for _ in range(40):
+        s.update(True)
+    assert s.scale_value == 2.0 ** 24
+    p = torch.nn.Parameter(torch.ones(4))
+    one = LossScaler(1.0, enabled=True)                   # fp16 with the scale at 1: the check still runs
+    p.grad = torch.tensor([1.0, float("nan"), 3.0, 4.0])
+    assert one.unscale_([p], check=True) is False
+    one.update(False)
+    assert one.scale_value == 1.0 and one.skipped_steps == 1
+    p.grad = torch.tensor([2.0, 4.0, float("inf"), 8.0])
+    s4 = LossScaler(4.0)
+    assert s4.unscale_([p], check=True) is False
+    p.grad = torch.tensor([2.0, 4.0, 6.0, 8.0])
+    z = torch.nn.Parameter(torch.ones(2, dtype=torch.complex64))
+    z.grad = torch.full((2,), 8 + 4j, dtype=torch.complex64)
+    assert s4.unscale_([p, z], check=True) is True
+    assert p.grad.tolist() == [0.5, 1.0, 1.5, 2.0] and z.grad.tolist() == [2 + 1j, 2 + 1j]
+    off = LossScaler.for_dtype(torch.bfloat16)
+    assert not off.enabled and off.scale(p.grad) is p.grad and off.unscale_([p], check=True) is True
+    off.update(False)
+    assert off.scale_value == 1.0

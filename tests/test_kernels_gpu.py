@@ -313,6 +313,33 @@ def test_conv3_bn_backward_statistics_epilogue(ops, dtype, cin, cout, dil, T, ti
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,KS,dil,T,B,nseg", [(320, 320, 3, 16, 360, 7, 3), (64, 160, 3, 1, 50, 5, 5), (320, 640, 3, 2, 200, 9, 2),
+                                                      (640, 1024, 1, 0, 131, 4, 1), (48, 40, 3, 8, 64, 3, 1)])
+def test_wgrad_flat_rows(ops, dtype, cin, cout, KS, dil, T, B, nseg):
+    """SDA_WGRAD_FLAT_ROWS: a segment of consecutive samples contracted as ONE run of rows (pad rows of dy are zero) in whole
+    K-chunks — same weight gradient as torch autograd (models.py:128-150 through autograd), and as the per-sample form."""
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(cin + 7 * cout + dil + T)
+    x = q(torch.randn(B, cin, T, generator=g), dtype).requires_grad_(True)
+    w = q(torch.randn(cout, cin, KS, generator=g) / math.sqrt(KS * cin), dtype).requires_grad_(True)
+    dy = q(torch.randn(B, cout, T, generator=g), dtype)
+    TF.conv1d(x, w, None, padding=dil if KS == 3 else 0, dilation=max(dil, 1)).backward(dy)
+    Cin_p, Cout_p = L.pad_channels(cin), L.pad_channels(cout)
+    dyb, xb = to_rows(ops, dy, dtype), to_rows(ops, x.detach(), dtype)      # (to_rows fills valid rows of a zeroed buffer)
+    edges = np.floor(np.linspace(0, B, nseg + 1)).astype(np.int32)
+    seg = torch.from_numpy(edges).to(DEV)
+    flat = ops.wgrad_gemm(dyb, xb, B=B, T=T, KS=KS, dil=dil, seg_start=seg, nseg=nseg, flat_rows=True)
+    per_sample = ops.wgrad_gemm(dyb, xb, B=B, T=T, KS=KS, dil=dil, seg_start=seg, nseg=nseg)
+    gw = ops.unpack_conv_wgrad(ops.reduce_slabs(flat), 1, cout, cin, KS, Cout_p, Cin_p)[0].cpu()
+    # operands are exact in every storage type (q), products accumulate in fp32: accumulation noise only, relative to the
+    # size of the sums (up to 1e2 here)
+    assert float((gw - w.grad).abs().max()) <= 1e-5 * float(w.grad.abs().max())
+    # the same products in a different summation order (chunks cut differently)
+    scale = float(per_sample.abs().max()) + 1e-12
+    assert float((flat - per_sample).abs().max()) <= 2e-5 * scale * math.sqrt(B * T / 64)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_wgrad_per_subject_segments(ops, dtype):
     from speech_decoding_amd import lib as L
     g = torch.Generator().manual_seed(8)

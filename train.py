@@ -111,7 +111,7 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
     scaler = LossScaler.for_dtype(brain_encoder.compute_dtype, float(args.get("fp16_loss_scale", 1024.0)),
                                   global_batch=int(args.batch_size), T=seq_T)                      # no-op unless fp16
 
-    fp16 = scaler.scale_value != 1.0
+    fp16 = scaler.enabled            # (not `scale != 1`: a scale halved down to 1, or fp16_loss_scale=1, keeps the overflow guard)
     one = torch.ones((), dtype=torch.float32, device=device)       # d loss / d loss, resident (autograd would fill one per step)
 
     def backward_and_step(loss):
@@ -120,8 +120,10 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
         if world > 1:        # (SUM of the still-scaled gradients: every rank then sees the same overflow, or none)
             allreduce_gradients(list(loss_func.parameters()) if brain_encoder.grads_are_reduced else params)
         # fp16 only: an activation gradient that overflowed to inf / NaN must not reach Adam — the finiteness check is a
-        # host read-back per step (fp16 is configs[4]'s dtype; bf16 / fp32 never take it), the step is skipped and the
-        # scale halved (amp.LossScaler.update, GradScaler's rule)
+        # host read-back per step of ONE device flag written by one fused launch (fp16 is configs[4]'s dtype; bf16 / fp32
+        # never take it), the step is skipped and the scale halved (amp.LossScaler.update, GradScaler's rule).  A skipped
+        # step is not a no-op for BatchNorm: its forward has already moved the running statistics and num_batches_tracked
+        # (as it would under torch.cuda.amp with nn.BatchNorm1d) — harmless for training, visible in a bit-for-bit replay
         ok = scaler.unscale_(params, check=fp16)
         scaler.update(ok)
         if ok:
