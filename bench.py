@@ -230,7 +230,12 @@ def main():
         X = torch.randn(B, C, T, generator=g, device=dev).clamp_(-20, 20)
         Y = torch.einsum("fc,bct->bft", Pm, X) + 0.5 * torch.randn(B, F, T, generator=g, device=dev)
         pool.append((X, Y.contiguous()))
+    # a fifth batch the steps never train on: the retrieval accuracy reported below is measured on IT (eval mode), i.e. on
+    # unseen segments — the quality half of BASELINE's metric — not on the batches the model has just been fitted to
+    Xh = torch.randn(B, C, T, generator=g, device=dev).clamp_(-20, 20)
+    Yh = (torch.einsum("fc,bct->bft", Pm, Xh) + 0.5 * torch.randn(B, F, T, generator=g, device=dev)).contiguous()
     subj_rng = np.random.RandomState(100 + rank)
+    subj_h = torch.from_numpy(np.random.RandomState(900 + rank).randint(0, S, size=B).astype(np.int32))
 
     ranks_acc = []
     one = torch.ones((), dtype=torch.float32, device=dev)
@@ -301,8 +306,20 @@ def main():
     ranks_acc.clear()
     dt, loss = timed(a.steps, a.warmup)                      # the contract number: K clean steps
     cnt = torch.cat([c.to(dev) for c in ranks_acc[-3:]]).float()
-    top10 = float((cnt < 10).float().mean())
+    top10_train = float((cnt < 10).float().mean())           # on the batches the last three steps trained on (for reference)
     final_loss = float(loss.detach())
+    # held-out retrieval accuracy (Classifier semantics, models.py:208-248; global candidates under data parallelism), outside
+    # the timed region: eval-mode forward of the unseen batch
+    enc.eval()
+    with torch.no_grad():
+        cnt_h = sda_loss.retrieval_ranks(Yh, enc(Xh, subj_h)).float()
+    enc.train()
+    top10 = float((cnt_h < 10).float().mean())
+    top1 = float((cnt_h < 1).float().mean())
+    if world > 1:
+        acc = torch.tensor([top10, top1], device=dev)
+        dist.all_reduce(acc)
+        top10, top1 = float(acc[0]) / world, float(acc[1]) / world
     # (fp16 runs with a STATIC loss scale here — no per-step host check inside the timed region; train.py checks every step.
     # An overflow would have poisoned the weights: verify after the fact that it did not)
     if not all(bool(torch.isfinite(torch.view_as_real(p) if p.is_complex() else p).all()) for p in params):
@@ -336,7 +353,10 @@ def main():
                                    f"F={F}, batch {B}/GPU, fwd+CLIP loss+top-k+bwd+Adam (BASELINE configs[1]"
                                    f"{' / configs[2]' if world == 8 else ''})",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}"},
-            "top10_acc": round(top10, 4), "final_loss": round(final_loss, 4),
+            "top10_acc": round(top10, 4), "top1_acc": round(top1, 4),
+            "top10_note": f"held-out batch of {B * world} segments never trained on (eval mode, chance = {10.0 / (B * world):.4f}); "
+                          f"on the last three TRAINING batches: {top10_train:.4f}",
+            "final_loss": round(final_loss, 4),
         }
         if dt_sync is not None:
             out["host_synced"] = {"value": round(B * world / dt_sync, 2), "ms_per_step": round(1e3 * dt_sync, 3),

@@ -64,28 +64,62 @@ def _flat_views(params: Iterable[torch.nn.Parameter]) -> List[torch.Tensor]:
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):
     """SUM all-reduce of every parameter gradient in flat fp32 buckets (few large collectives: xGMI rings
-    are per-link bound, so fewer, larger messages win)."""
+    are per-link bound, so fewer, larger messages win).  The gradients are MOVED into the bucket: after the call each
+    `.grad` is a view of its bucket (one pack, no copy back); a single gradient is reduced in place."""
     if active_group() is None and group is None:
         return
-    views = _flat_views(list(params))
-    bucket, size = [], 0
+    plist = [p for p in params]
+    _flat_views(plist)                                    # materialises missing gradients (zeros)
+    bucket: List[torch.nn.Parameter] = []
+    size = 0
+
     def flush():
         nonlocal bucket, size
         if not bucket:
             return
-        flat = torch.cat(bucket)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for v in bucket:
-            v.copy_(flat[off: off + v.numel()])
-            off += v.numel()
+        if len(bucket) == 1:
+            g = bucket[0].grad
+            dist.all_reduce(torch.view_as_real(g) if g.is_complex() else g, op=dist.ReduceOp.SUM, group=group)
+        else:
+            # (every entry starts at an even float offset: a complex gradient is viewed as complex inside the bucket)
+            parts, offs, off = [], [], 0
+            for p in bucket:
+                v = (torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad).reshape(-1)
+                if off % 2:
+                    parts.append(v.new_zeros(1))
+                    off += 1
+                offs.append(off)
+                parts.append(v)
+                off += v.numel()
+            flat = torch.cat(parts)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            for p, o in zip(bucket, offs):
+                g = p.grad
+                v = flat[o: o + g.numel() * (2 if g.is_complex() else 1)]
+                p.grad = torch.view_as_complex(v.view(*g.shape, 2)) if g.is_complex() else v.view(g.shape)
         bucket, size = [], 0
-    for v in views:
-        bucket.append(v)
-        size += v.numel() * 4
+    for p in plist:
+        bucket.append(p)
+        size += p.grad.numel() * (8 if p.grad.is_complex() else 4)
         if size >= bucket_bytes:
             flush()
     flush()
+
+
+def seed_numpy_all_ranks(seed: int = None, group=None) -> int:
+    """Put NumPy's GLOBAL generator in the same state on every rank: SpatialDropout draws its centre from it once per
+    training forward (models.py:81) and the batch — hence the centre — is global.  seed=None: rank 0 draws one and
+    broadcasts it.  Returns the seed.  (A no-op without torch.distributed; callers that draw from np.random elsewhere must
+    do so on all ranks alike, or use BrainEncoder.drop_centre_sync = "broadcast".)"""
+    import numpy as np
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if seed is not None:
+            np.random.seed(int(seed))
+        return -1 if seed is None else int(seed)
+    box = [int(seed) if seed is not None else int(np.random.randint(0, 2 ** 31 - 1))]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    np.random.seed(box[0])
+    return box[0]
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):

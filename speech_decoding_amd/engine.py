@@ -114,6 +114,11 @@ class EncoderEngine:
         # (measured in the step: +2 %; with one flat workgroup per CU: +7 %)
         self.flat_tiles_backward = False
         self.flat_backward_one_per_cu = False
+        # CU partition for backward (experiment, default off): k > 0 gives the data-gradient chain (the stream backward() is
+        # called on hands over to a CU-masked stream) k of the 8 XCDs and the weight-gradient stream the other 8 - k, instead
+        # of letting the two streams' workgroups compete for every CU (hipExtStreamCreateWithCUMask)
+        self.cu_partition_xcds = 0
+        self._part = {}
         self._side = {}
         self._const = {}                     # persistent operand buffers (composed SubjectBlock matrices)
 
@@ -434,7 +439,59 @@ class EncoderEngine:
         return ctx
 
     # ------------------------------------------------------------------ backward
+    def _partition_streams(self, dev, k: int):
+        """(main, side, main_cus): two CU-masked streams.  Bit i of a mask is CU (i // 8) of XCD (i % 8) — the runtime deals
+        consecutive indices round-robin to the XCDs, and an XCD whose share of the mask is EMPTY runs unrestricted
+        (tools/probes/cumask_probe.py: masks `i % 8 < 1` and `i % 8 < 4` change nothing, `i < 128` halves every XCD) — so a
+        partition is a subset of every XCD's CUs: the first k / 8 of each XCD's 32 (k = 5: 20 CUs x 8 XCDs) against the rest.
+        k = 8 + m (diagnostic): both streams unrestricted."""
+        key = (str(dev), k)
+        if key not in self._part:
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            per_xcd = cus // 8
+            bits_a = [1 if (i // 8) < (per_xcd * k) // 8 else 0 for i in range(cus)]
+            if k >= 8:
+                bits_a = [1] * cus
+            if k == 9:        # (diagnostic) the same hand-over on two ordinary streams
+                self._part[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), cus)
+                return self._part[key]
+            streams = []
+            for bits in (bits_a, [1 - b for b in bits_a] if k < 8 else bits_a):
+                words = [sum(bits[32 * w + j] << j for j in range(32) if 32 * w + j < cus) for w in range((cus + 31) // 32)]
+                streams.append(torch.cuda.ExternalStream(ops.stream_create_cumask(words), device=dev))
+            self._part[key] = (streams[0], streams[1], sum(bits_a))
+        return self._part[key]
+
     def backward(self, P: Dict[str, torch.Tensor], ctx: EncoderCtx, dZt: torch.Tensor) -> Dict[str, torch.Tensor]:
+        k = int(self.cu_partition_xcds)
+        if not (0 < k <= 9 and self.wgrad_side_stream):
+            return self._backward(P, ctx, dZt)
+        dev = dZt.device
+        outer = torch.cuda.current_stream(dev)
+        main_p, side_p, main_cus = self._partition_streams(dev, k)
+        ev = torch.cuda.Event()
+        ev.record(outer)
+        main_p.wait_event(ev)
+        saved_side = self._side.get(str(dev))
+        self._side[str(dev)] = side_p
+        old_limit = L.load().sda_set_cu_limit(main_cus)          # persistent grids launched below size themselves for the partition
+        try:
+            with torch.cuda.stream(main_p):
+                grads = self._backward(P, ctx, dZt)
+                done = torch.cuda.Event()
+                done.record(main_p)
+        finally:
+            L.load().sda_set_cu_limit(old_limit)
+            if saved_side is not None:
+                self._side[str(dev)] = saved_side
+            else:
+                self._side.pop(str(dev), None)
+        # (no record_stream: blocks allocated on main_p are consumed on `outer` strictly behind `done`, and the next backward's
+        # main_p work starts behind an event of `outer` — record_stream would only make the allocator hold them back)
+        outer.wait_event(done)
+        return grads
+
+    def _backward(self, P: Dict[str, torch.Tensor], ctx: EncoderCtx, dZt: torch.Tensor) -> Dict[str, torch.Tensor]:
         if ctx.gen != self._gen and self.reuse_workspace:
             raise L.SdaError("the activation workspace of this forward was overwritten by a later forward of the same "
                              "encoder; call backward before the next training-mode forward, or set "

@@ -197,6 +197,8 @@ class BrainEncoder(nn.Module):
         self.sync_batchnorm = True          # under torch.distributed: BN statistics over the global batch
         self._engine: Optional[EncoderEngine] = None
         self._fixed_centre: Optional[int] = None
+        self.drop_centre_sync = "seed"        # under data parallelism: "seed" (identical np.random on all ranks, checked) | "broadcast"
+        self._centre_draws = 0
         self._param_names = self._build_names()
 
     # ---- parameter plumbing -------------------------------------------------------------
@@ -268,11 +270,29 @@ class BrainEncoder(nn.Module):
             mask = sa.device_masks(X.device)[centre]            # (C, C) table resident on the device: no upload
             group = _dp_group()
             if group is not None and self._fixed_centre is None:
-                mask = mask.clone()             # the cached table must not be overwritten by the broadcast
-                # "same drop centre for all samples in batch" — the batch is global: rank 0's mask wins.
-                # Broadcasting the device mask (not the index) keeps the host free of a per-step sync.
+                # "same drop centre for all samples in batch" (models.py:69) — the batch is global, so every rank must use
+                # the same centre.  NumPy's global generator is seeded identically on all ranks
+                # (distributed.seed_numpy_all_ranks; train.py / bench.py do it) and nothing else draws from it, so every
+                # rank draws the same centre by itself: no collective in front of the forward.  That lockstep is CHECKED —
+                # on the first data-parallel forward and every 256th after it (one small all-gather + a host read-back) —
+                # and a divergence is an error, not a silent semantic change.  drop_centre_sync = "broadcast" restores the
+                # per-step broadcast of rank 0's mask (a latency-bound collective on the critical path) for callers that
+                # draw from np.random elsewhere.
                 import torch.distributed as dist
-                dist.broadcast(mask, src=0, group=group)
+                if self.drop_centre_sync == "broadcast":
+                    mask = mask.clone()         # the cached table must not be overwritten by the broadcast
+                    dist.broadcast(mask, src=0, group=group)
+                else:
+                    if self._centre_draws % 256 == 0:
+                        mine = torch.tensor([centre], dtype=torch.int32, device=X.device)
+                        allc = torch.empty(dist.get_world_size(group), dtype=torch.int32, device=X.device)
+                        dist.all_gather_into_tensor(allc, mine, group=group)
+                        if len(set(allc.tolist())) != 1:
+                            raise L.SdaError(f"SpatialDropout centres differ across ranks ({allc.tolist()}): NumPy's global generator "
+                                             "is out of step — call speech_decoding_amd.distributed.seed_numpy_all_ranks() after "
+                                             "init_process_group and draw from np.random on all ranks alike, or set "
+                                             "brain_encoder.drop_centre_sync = 'broadcast'")
+                    self._centre_draws += 1
         params = self._ordered_params()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # (grad mode is off inside Function.forward)
         return _EncoderFn.apply(self, X, subject_idxs, mask, need_grad, *params)

@@ -28,6 +28,15 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+def stream_create_cumask(words) -> int:
+    """A HIP stream restricted to the CUs set in `words` (32 CUs per word); returns the hipStream_t as an integer for
+    torch.cuda.ExternalStream.  Created in this process; never destroyed (a handful per run)."""
+    arr = (C.c_uint32 * len(words))(*[int(w) & 0xFFFFFFFF for w in words])
+    out = C.c_void_p()
+    L.check(L.load().sda_stream_create_cumask(arr, len(words), C.byref(out)), "stream_create_cumask")
+    return int(out.value)
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:

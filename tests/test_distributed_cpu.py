@@ -20,10 +20,18 @@ def _worker(rank, world, port, fn, ret):
         dist.destroy_process_group()
 
 
+def _free_port():
+    """A port the OS hands out (a pid-derived one can collide with another test process)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def run2(fn):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, fn, ret)) for r in range(2)]
     for p in procs:
         p.start()
@@ -110,3 +118,34 @@ def _syncbn(rank, world):
 def test_synchronised_batchnorm_statistics():
     out = run2(_syncbn)
     assert out[0] and out[1]
+
+
+def _seed_and_sampler(rank, world):
+    """SpatialDropout's centre under data parallelism: NumPy's global generator in lockstep on all ranks
+    (distributed.seed_numpy_all_ranks), and the sampler shards of data.ShardedRandomSampler."""
+    import numpy as np
+    from speech_decoding_amd.data import ShardedRandomSampler
+    from speech_decoding_amd.distributed import allreduce_gradients, seed_numpy_all_ranks
+    np.random.seed(1000 + rank)                                      # ranks start out of step
+    seed = seed_numpy_all_ranks()
+    centres = [int(np.random.randint(208)) for _ in range(5)]
+    fixed = seed_numpy_all_ranks(77)
+    centres2 = [int(np.random.randint(208)) for _ in range(3)]
+    mine = [b.tolist() for b in ShardedRandomSampler(50, 8, 3, rank, world, seed=9)]
+    # bucketed all-reduce leaves every .grad a view of its bucket (no copy back) with the summed values
+    a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2, dtype=torch.cfloat))
+    a.grad, b.grad = torch.full((3,), float(rank + 1)), torch.full((2,), complex(rank + 1, 1.0))
+    allreduce_gradients([a, b])
+    same_storage = a.grad.untyped_storage().data_ptr() == torch.view_as_real(b.grad).untyped_storage().data_ptr()
+    return seed, centres, fixed, centres2, mine, a.grad.tolist(), b.grad.tolist(), same_storage
+
+
+def test_numpy_lockstep_and_sampler_shards():
+    from speech_decoding_amd.data import ShardedRandomSampler
+    out = run2(_seed_and_sampler)
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]          # same broadcast seed, same centres afterwards
+    assert out[0][2] == out[1][2] == 77 and out[0][3] == out[1][3]
+    whole = [b.tolist() for b in ShardedRandomSampler(50, 8, 3, 0, 1, seed=9)]
+    assert [x + y for x, y in zip(out[0][4], out[1][4])] == whole
+    for r in (0, 1):
+        assert out[r][5] == [3.0, 3.0, 3.0] and out[r][6] == [complex(3, 2)] * 2 and out[r][7]

@@ -126,3 +126,42 @@ def test_other_configs_per_rank_batch_eval_forward_sampled_against_oracle(name, 
     assert rel_l2(got, Zo) < REL_EVAL[dtype], rel_l2(got, Zo)
     assert float((got - Zo).abs().max()) <= MAX_EVAL[dtype] * float(Zo.abs().max())
     enc.engine.release_workspace()
+
+
+def _free_host_gib():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:                                                 # noqa: BLE001
+        return 0.0
+
+
+@pytest.mark.parametrize("name,Cc,Ss,Tt,dtype", [("configs[3] per-rank batch: 60 ch, 1 subject, batch 512, bf16", 60, 1, 360, "bf16"),
+                                                 ("configs[4] per-rank batch: 306 ch, T=1000, 100 subjects, batch 512, fp16", 306, 100, 1000, "fp16")])
+def test_other_configs_per_rank_batch_train_step_vs_oracle(name, Cc, Ss, Tt, dtype, record_property):
+    """BASELINE.json configs[3] / configs[4] at the batch ONE rank of the 8-GPU run holds (512 segments), TRAINING step in the
+    dtype the config names: embeddings, loss, temperature gradient and every parameter gradient against the oracle fed the same
+    rounded operands (reference: models.py:191-196 + utils/loss.py:58-79 through autograd).  This is the backward geometry the
+    small fixtures never reach: weight-gradient sample segments at B = 512 / T = 1000, slab sums, one subject cut into r > 1
+    K-slices (S = 1), ~36 GiB of workspace at configs[4].  The oracle keeps every activation for autograd in fp32 on the host;
+    where the host cannot hold batch 512 the test runs the largest batch that fits (a multiple of 64, at least 128) and says so."""
+    per_sample = Tt * (45 * D2 + 6 * F) * 4 * 1.3 / 2 ** 30            # GiB the oracle's autograd graph needs per sample
+    free = _free_host_gib()
+    Bb = 512
+    while Bb > 128 and Bb * per_sample + 6 > free:
+        Bb -= 64
+    if Bb * per_sample + 6 > free:
+        pytest.skip(f"{name}: the CPU oracle needs ~{128 * per_sample + 6:.0f} GiB of host memory even at batch 128 ({free:.0f} free)")
+    record_property("batch", Bb)
+    if Bb != 512:
+        warnings.warn(f"{name}: host memory ({free:.0f} GiB free) holds the oracle at batch {Bb}, not 512")
+    loc = O.synthetic_positions(Cc, seed=1)
+    P = O.seeded_params(Cc, Ss, D1, D2, F, K, seed=1, loc=loc)
+    args = make_args(Cc, Ss, D1, D2, 512, K, True, loc.numpy(), dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        enc, lossf, clf = build(args, P, [5.1])
+    X, Y, subj = O.synthetic_batch(Bb, Cc, Tt, F, Ss, seed=77)
+    report = check_lowprec_step(enc, lossf, P, [5.1], X, Y, subj, loc, 3, dtype, scale_for=(Bb, Tt))
+    assert len([k for k in report if k.startswith("grad ")]) >= 40
+    enc.engine.release_workspace()

@@ -237,3 +237,20 @@ def test_loss_scaler_guards_fp16_whatever_the_scale_and_never_grows_below_its_st
     assert not off.enabled and off.scale(p.grad) is p.grad and off.unscale_([p], check=True) is True
     off.update(False)
     assert off.scale_value == 1.0
+
+
+def test_sharded_random_sampler_is_the_global_sampler_cut_into_rank_slices():
+    """get_dataloaders.py:57-62 (RandomSampler(replacement=True, num_samples=updates * batch_size)) consumed in batches: the
+    concatenation of the ranks' slices is the single-process batch, for every update, whatever the world size."""
+    from speech_decoding_amd.data import ShardedRandomSampler
+    whole = [b.tolist() for b in ShardedRandomSampler(97, 24, 5, 0, 1, seed=11)]
+    assert len(whole) == 5 and all(len(b) == 24 and max(b) < 97 for b in whole)
+    for world in (2, 3, 4):
+        parts = [[b.tolist() for b in ShardedRandomSampler(97, 24, 5, r, world, seed=11)] for r in range(world)]
+        assert [sum((parts[r][u] for r in range(world)), []) for u in range(5)] == whole
+    assert any(len(set(b)) < len(b) for b in [x.tolist() for x in ShardedRandomSampler(10, 8, 20, seed=1)])     # with replacement
+    norep = [b.tolist() for b in ShardedRandomSampler(30, 8, 4, seed=1, replacement=False)]
+    assert all(len(set(b)) == 8 for b in norep)
+    import pytest
+    with pytest.raises(ValueError):
+        ShardedRandomSampler(10, 9, 1, 0, 2)

@@ -38,6 +38,7 @@ def _free_host_gib():
     ("configs[2] 2048 x 256, T=360", 8, 256, 360, "bf16", None, (0, 5)),
     ("configs[2] 2048 x 256, T=360, exact path", 8, 256, 360, "fp32", (2,), (2,)),
     ("configs[4] 4096 x 512, T=1000", 8, 512, 1000, "fp16", (3,), (3,)),
+    ("configs[3] 4096 x 512, T=360 (60-channel EEG: the loss block only sees F x T)", 8, 512, 360, "bf16", (6,), (6,)),
 ])
 def test_global_negative_loss_block_at_full_size(name, world, Bn, T, dtype, distinct, check):
     """distinct = ranks whose brain columns are their own data (None: all); the other ranks all hold the SAME block of

@@ -207,3 +207,39 @@ def test_short_training_curve_at_real_widths_tracks_the_fp32_oracle(dtype, tmp_p
         assert abs(got["test_loss"] - ref["test_loss"]) <= band * max(1.0, ref["test_loss"]), msg
         assert abs(got["temp"] - ref["temp"]) < (2e-3 if dtype == "bf16" else 1e-4), msg
     assert want[-1]["train_loss"] < want[0]["train_loss"], msg
+
+
+def test_resident_feed_batch_equals_the_host_pipeline():
+    """data=resident: a batch of the per-rank feed (speech_decoding_amd/data.py) equals what the reference's input path does
+    on the host — gwilliams2022.py:129-142 (random recording of the segment's task, window at the segment's onset, subject of
+    that recording) then :640-661 (baseline correction, robust scaling, clamp; restated by oracle.collate_batch, itself pinned
+    on a fixture produced by the reference's preproc_utils)."""
+    from speech_decoding_amd.data import synthetic_resident_dataset
+    args, _ = tiny_args("Gwilliams2022")
+    feed, train_idx, test_idx = synthetic_resident_dataset(args, "cuda:0", n_segments=40, seed=1234)
+    assert len(feed) == 40 and len(train_idx) == 28 and len(test_idx) == 12 and not set(train_idx) & set(test_idx)
+    idx = np.array([3, 17, 17, 39, 0, 21])                        # (duplicates are allowed: RandomSampler(replacement=True))
+    twin = np.random.RandomState(1234 + 17)                      # the feed's own generator, replayed
+    X, Y, subj = feed.batch(idx)
+    T, nb = 40, 10
+    rec = [int(twin.choice(feed.by_task[int(feed.seg_task[i])])) for i in idx]
+    win = torch.stack([feed.rs.sessions[r][:, int(feed.onsets[r][feed.seg_in_task[i]]):][:, :T].cpu() for r, i in zip(rec, idx)])
+    want = O.collate_batch(win, nb, 20.0, True)
+    np.testing.assert_allclose(X.cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-5)
+    assert torch.equal(Y.cpu(), feed.Y.cpu()[idx]) and subj.dtype == torch.int32
+    assert subj.tolist() == [int(feed.rec_subject[r]) for r in rec]
+
+
+def test_training_driver_on_the_resident_feed(tmp_path, monkeypatch):
+    """train.py with data=resident: sampler shard -> segment gather + collate on the GPU -> the training step; the loss
+    comes down and the held-out split is ranked."""
+    import train as T
+    monkeypatch.chdir(tmp_path)
+    args, _ = tiny_args("Gwilliams2022")
+    args["data"], args["epochs"], args["updates_per_epoch"], args["lr"] = "resident", 6, 4, 3e-3
+    torch.manual_seed(0)
+    np.random.seed(0)
+    hist, enc, lossf = T.run(args, log=lambda *a: None)
+    assert len(hist) == 6 and all(np.isfinite(h["train_loss"]) and np.isfinite(h["test_loss"]) for h in hist)
+    assert hist[-1]["train_loss"] < 0.9 * hist[0]["train_loss"]
+    assert 0.0 <= hist[-1]["testTop10acc"] <= 1.0

@@ -84,8 +84,34 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
     if args.get("reproducible", False):
         np.random.seed(0)
         torch.manual_seed(0)
+    elif world > 1:
+        # SpatialDropout's centre comes from NumPy's global generator (models.py:81) and must be the same on every rank
+        from speech_decoding_amd.distributed import seed_numpy_all_ranks
+        seed_numpy_all_ranks()
 
-    if train_batches is None:
+    # data=pool (default): a resident pool of ready-made segments, every rank slicing its shard out of the global batch;
+    # data=resident: the reference's own input path on the GPU — recordings resident in HBM, RandomSampler(replacement=True)
+    # (get_dataloaders.py:48-87) cut into rank shards so that no rank materialises another rank's samples, window gather +
+    # baseline correction + robust scaling + clamp (gwilliams2022.py:129-142,640-661) as one kernel per batch
+    feeds_local_shards = False
+    if train_batches is None and str(args.get("data", "pool")) == "resident":
+        from speech_decoding_amd.data import ShardedRandomSampler, synthetic_resident_dataset
+        n_seg = int(args.get("synthetic_segments", 4 * int(args.batch_size)))
+        feed, train_idx, test_idx = synthetic_resident_dataset(args, device, n_segments=n_seg, seed=1234)
+        updates = int(args.get("updates_per_epoch", max(1, len(train_idx) // int(args.batch_size))))
+        epoch_no = [0]
+
+        def train_batches():
+            sampler = ShardedRandomSampler(len(train_idx), int(args.batch_size), updates, rank, world, seed=4321 + epoch_no[0])
+            epoch_no[0] += 1
+            for idx in sampler:
+                yield feed.batch(train_idx[idx.numpy()])
+
+        def test_batch():
+            lo, hi = shard_range(len(test_idx), rank, world)
+            return feed.batch(test_idx[lo:hi])
+        feeds_local_shards = True
+    elif train_batches is None:
         n_seg = int(args.get("synthetic_segments", 4 * int(args.batch_size)))
         data = SyntheticSegments(args, n_seg, device, seed=1234)
         updates = int(args.get("updates_per_epoch", max(1, len(data.train_idx) // int(args.batch_size))))
@@ -142,7 +168,7 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
         loss = None
         def local_shard(batch):
             X, Y, subject_idxs = batch
-            if world > 1:
+            if world > 1 and not feeds_local_shards:
                 lo, hi = shard_range(X.shape[0], rank, world)
                 X, Y, subject_idxs = X[lo:hi], Y[lo:hi], subject_idxs[lo:hi]
             return X, Y, subject_idxs
@@ -183,7 +209,7 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
         te_loss, te_top1, te_top10 = [], [], []
         with torch.no_grad():
             X, Y, subject_idxs = test_batch()
-            if world > 1:
+            if world > 1 and not feeds_local_shards:
                 lo, hi = shard_range(X.shape[0], rank, world)
                 X, Y, subject_idxs = X[lo:hi], Y[lo:hi], subject_idxs[lo:hi]
             Z = brain_encoder(X, subject_idxs)
