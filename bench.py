@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--timer-steps", type=int, default=3, help="instrumented steps run after the timed region")
     ap.add_argument("--no-prefetch-ahead", action="store_true", help="N > 1: gather each step's speech rows at its own start")
     ap.add_argument("--no-host-sync-leg", action="store_true", help="skip the extra loop that reads loss/ranks back every step")
+    ap.add_argument("--coll-timer-steps", type=int, default=0, help="N > 1: extra steps (after the timed region) with HIP-event "
+                    "brackets around every collective; adds `collectives_us_per_step` to the JSON line")
     return ap.parse_args()
 
 
@@ -343,6 +345,19 @@ def main():
         fence()
         ops.TIMER = None
 
+    coll = None
+    if world > 1 and a.coll_timer_steps > 0:                 # what each collective costs the stream that waits for it
+        from speech_decoding_amd.distributed import CollectiveTimer
+        fence()
+        ct = CollectiveTimer().install()
+        base = nxt + (a.timer_steps if timer is not None else 0)
+        for i in range(a.coll_timer_steps):
+            step(base + i)
+        fence()
+        ct.uninstall()
+        coll = {k: {"calls_per_step": round(n / a.coll_timer_steps, 2), "us_per_step": round(us / a.coll_timer_steps, 1)}
+                for k, (n, us) in sorted(ct.summary().items())}
+
     if rank == 0:
         out = {
             "metric": "train segments/sec (Gwilliams2022 208ch x 360, top-10 retrieval acc alongside)",
@@ -374,6 +389,8 @@ def main():
                                "measured": f"HIP events around every launch in {a.timer_steps} extra steps after the timed region"}
             out["kernel_time_ms_per_step"] = {f"{k[0]}<{k[1]},{k[2]},{k[3]}>": round(v[2] / a.timer_steps, 3) for k, v in summ.items()}
             out["kernel_tflops"] = {f"{k[0]}<{k[1]},{k[2]},{k[3]}>": round(v[1] / (v[2] * 1e-3) / 1e12, 1) for k, v in summ.items() if v[2] > 0}
+        if coll is not None:
+            out["collectives_us_per_step"] = coll
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out), flush=True)

@@ -162,3 +162,68 @@ def combine_row_stats(allp: torch.Tensor):
     row_sum = (allp[:, 1] * torch.exp(allp[:, 0] - gmax)).sum(dim=0)
     lse = gmax + torch.log(row_sum)
     return lse if allp.shape[1] < 3 else (lse, allp[:, 2].sum(dim=0))
+
+
+class CollectiveTimer:
+    """Diagnostics for the scaling runs: HIP-event brackets around every torch.distributed collective of a few steps, on the
+    stream that issues it (and, for async ones, around the wait) — what each collective costs the stream that has to wait
+    for it, grouped by (operation, payload size).  install() wraps dist.all_reduce / all_gather_into_tensor / broadcast;
+    uninstall() restores them; summary() -> {label: (calls, total_us)}.  Never installed inside a timed region."""
+
+    OPS = ("all_reduce", "all_gather_into_tensor", "broadcast")
+
+    def __init__(self):
+        self.records = []
+        self._saved = {}
+
+    def _wrap(self, name, fn):
+        timer = self
+
+        def wrapped(*args, **kw):
+            t = args[1] if name == "all_gather_into_tensor" else args[0]
+            label = f"{name} {t.numel() * t.element_size()} B"
+            if not t.is_cuda:
+                return fn(*args, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work = fn(*args, **kw)
+            if work is not None and kw.get("async_op"):
+                wait = work.wait
+
+                def timed_wait(*a, **k):
+                    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    w0.record()
+                    r = wait(*a, **k)
+                    w1.record()
+                    timer.records.append((label + " (wait of async)", w0, w1))
+                    return r
+                try:
+                    work.wait = timed_wait
+                except AttributeError:
+                    pass
+                e1.record()
+                timer.records.append((label + " (async issue)", e0, e1))
+                return work
+            e1.record()
+            timer.records.append((label, e0, e1))
+            return work
+        return wrapped
+
+    def install(self):
+        for name in self.OPS:
+            self._saved[name] = getattr(dist, name)
+            setattr(dist, name, self._wrap(name, self._saved[name]))
+        return self
+
+    def uninstall(self):
+        for name, fn in self._saved.items():
+            setattr(dist, name, fn)
+        self._saved = {}
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for label, e0, e1 in self.records:
+            n, us = out.get(label, (0, 0.0))
+            out[label] = (n + 1, us + e0.elapsed_time(e1) * 1e3)
+        return out

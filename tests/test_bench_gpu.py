@@ -32,7 +32,7 @@ def test_bench_spawns_two_ranks_and_prints_one_json_line():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-           "--batch", "32", "--timer-steps", "1"]
+           "--batch", "32", "--timer-steps", "1", "--coll-timer-steps", "2"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     log_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(log_dir):
@@ -47,6 +47,12 @@ def test_bench_spawns_two_ranks_and_prints_one_json_line():
     assert line["value"] == pytest.approx(64 * 3 / (line["ms_per_step"] * 3e-3), rel=1e-3)
     assert "roofline" in line and "cpu_baseline" not in line          # the CPU leg is rank 0's at N = 1 only
     assert 0.0 <= line["top10_acc"] <= 1.0 and line["final_loss"] == line["final_loss"]
+    assert "held-out" in line["top10_note"]
+    # the collective brackets of tools/scale_run.sh: 20 SyncBN statistics all-reduces per step (10 forward + 10 backward), the
+    # speech-row all-gather, the loss's row-statistics all-gather, the gradient buckets
+    coll = line["collectives_us_per_step"]
+    assert sum(v["calls_per_step"] for k, v in coll.items() if k.startswith("all_reduce 2560 B")) >= 20
+    assert any(k.startswith("all_gather_into_tensor") for k in coll) and all(v["us_per_step"] >= 0 for v in coll.values())
 
 
 def test_bench_single_gpu_line_carries_the_contract_fields():

@@ -34,8 +34,26 @@ def tiny_args(dataset):
     return args, loc
 
 
-def oracle_loop(args, loc, init_state, data_cpu, updates=2):
+class cpu_threads:
+    """torch CPU threads for the oracle loop: toy-width tensors are far below the size where a thread pool pays — with every
+    core of the GPU box's host in the pool a 200-step toy loop took 180 s, with two threads it takes under 10."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        torch.set_num_threads(self.n)
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.old)
+
+
+def oracle_loop(args, loc, init_state, data_cpu, updates=2, threads=None):
     """train.py:166-233 restated on the oracle (CPU, fp32)."""
+    if threads is not None:
+        with cpu_threads(threads):
+            return oracle_loop(args, loc, init_state, data_cpu, updates)
     names = [k for k, v in init_state.items() if (v.is_floating_point() or v.is_complex()) and "running" not in k
              and not k.endswith((".cos", ".sin"))]
     P = {k: v.clone() for k, v in init_state.items()}
@@ -80,7 +98,7 @@ def test_training_driver_matches_oracle_loop(dataset, tmp_path, monkeypatch):
     init = {k: v.clone() for k, v in BrainEncoder(args).state_dict().items()}      # same seed => same init inside run()
     data_cpu = T.SyntheticSegments(args, 40, "cpu", seed=1234)
     np.random.seed(0)
-    want, want_params = oracle_loop(args, loc, init, data_cpu)
+    want, want_params = oracle_loop(args, loc, init, data_cpu, threads=2)
     torch.manual_seed(0)
     np.random.seed(0)
     lines = []
@@ -142,7 +160,7 @@ def test_200_step_training_curve_of_16bit_paths_tracks_the_fp32_oracle(dtype, tm
 
     def run_oracle():
         np.random.seed(0)
-        return oracle_loop(args, loc, init, data_cpu, updates=10)[0]
+        return oracle_loop(args, loc, init, data_cpu, updates=10, threads=2)[0]
     want = oracle_curve("toy widths, 200 steps", run_oracle)
     torch.manual_seed(0)
     np.random.seed(0)
@@ -191,7 +209,7 @@ def test_short_training_curve_at_real_widths_tracks_the_fp32_oracle(dtype, tmp_p
 
     def run_oracle():
         np.random.seed(0)
-        return oracle_loop(args, loc, init, data_cpu, updates=6)[0]
+        return oracle_loop(args, loc, init, data_cpu, updates=6, threads=min(32, os.cpu_count() or 8))[0]
     want = oracle_curve("real widths, 24 steps", run_oracle)
     torch.manual_seed(0)
     np.random.seed(0)
