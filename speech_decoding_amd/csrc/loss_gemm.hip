@@ -64,39 +64,86 @@ __global__ __launch_bounds__(256, 2) void clip_dz_kernel(const E* __restrict__ G
   // LDS-DMA of one Y tile: 32 pieces of 8 rows x 128 B, lane-linear in LDS, chunk swizzle on the source (tr_operand.h)
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   const int prow = lane >> 3, pchunk = lane & 7;
-  auto stage = [&](int tile, int buf) {
-    const long k0 = (long)tile * DZ_KT;
+  // (scalar base = the tile's first column, ONE 32-bit per-lane offset per piece, fixed for the kernel: eight registers
+  // instead of eight 64-bit pointers — those were spilled, and a scratch reload inside the loop is a compiler-generated
+  // vmcnt(0), i.e. a drained DMA pipeline)
+  uint32_t yoff[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int piece = wid * 8 + p;
-      const int row = piece * 8 + prow;
-      const int src_row = row < Bm ? row : Bm - 1;     // (rows past the batch meet zero coefficients: any finite data will do)
-      const int c = pchunk ^ chunk_xor<E, 128>(row);
-      lds_dma16(Y + (size_t)src_row * row_elems + k0 + c * 8, lds_base + buf * DZ_YB + piece * 1024);
-    }
+  for (int p = 0; p < 8; ++p) {
+    const int row = (wid * 8 + p) * 8 + prow;
+    const int src_row = row < Bm ? row : Bm - 1;       // (rows past the batch meet zero coefficients: any finite data will do)
+    yoff[p] = (uint32_t)(((size_t)src_row * row_elems + (size_t)((pchunk ^ chunk_xor<E, 128>(row)) * 8)) * sizeof(E));
+  }
+  auto stage = [&](int tile, int buf) {
+    const E* yk = Y + (long)tile * DZ_KT;
+    const uint32_t dst = lds_base + buf * DZ_YB + wid * 8 * 1024;
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(yoff[p]), "s"(yk), "s"(dst + p * 1024) : "memory");
   };
 
   float* stg = reinterpret_cast<float*>(smem + 2 * DZ_YB + wid * DZ_STG);
   const float os = out_scale ? out_scale[0] : 1.f;
+  // ---- the tile loop, with every vector-memory operation counted by hand.
+  // hipcc knows nothing of the LDS-DMA issued from asm, so ANY load it does know of poisons the pipeline: its wait for that
+  // load is "all but my own younger loads", which drains the next tile's DMA issued in between (the first version read Z with
+  // ordinary loads: by the end of a tile's epilogue the prefetch had been waited for — 3.9 TB/s).  So Z, too, is loaded from
+  // asm, the per-column factors are hoisted out of the loop, and the only compiler-visible memory operations left in it are
+  // the stores, which nothing waits for.  Per tile and wave, in issue order:
+  //     [L loads of Z (this tile)] [D = 8 LDS-DMA pieces (next tile; 0 on the last)] ... [L stores, one per epilogue pass]
+  // with L = 2 * nv, nv = the wave's 16-column blocks that hold at least one valid column (a pass without one is skipped:
+  // wave-uniform, so the counts are exact).  The pass that needs Z load q has seen q stores since: the operations younger
+  // than that load are (L - 1 - q) + D + q = L - 1 + D — one literal per tile; at the top of a tile the D pieces issued
+  // during the previous one are followed by its L stores: vmcnt(L) leaves exactly those stores in flight.
+  const int jr = lane >> 2, c8 = lane & 3;             // row of an epilogue patch, which 8 of its 32 columns
+  int nv = (Bn - jwave + 15) >> 4;
+  nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+  nv = __builtin_amdgcn_readfirstlane(nv);
+  float csr[4], rsr[4];
+  uint32_t zoff[4];                                    // this lane's byte offset into Z / dZ per 16-column block (rows past the matrix: the last row)
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int j = jwave + n * 16 + jr;
+    csr[n] = (j < Bn && cscale) ? cscale[j] : 1.f;
+    rsr[n] = j < Bn ? rscale[j] : 0.f;
+    zoff[n] = (uint32_t)(((size_t)(j < Bn ? j : Bn - 1) * row_elems + c8 * 8) * sizeof(E));
+  }
+  // (waves with a ragged last block — nv < 4, the edge of a batch that is not a multiple of 64 — take vmcnt(0): always
+  // safe, and they are few; the full waves get the literals)
+  auto wait_later = [&](bool more) {                    // vmcnt(2 nv - 1 + (more ? 8 : 0)) for nv == 4
+    if (nv == 4) {
+      if (more) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
   int tile = blockIdx.x, buf = 0;
   if (tile < ntiles) stage(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first tile (and the coefficient loads above)
+  bool first = true;
   for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tile have landed (and its stores have left)
+    if (!first) {                                       // this wave's pieces of the tile have landed; the previous tile's stores may fly on
+      if (nv == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    first = false;
     __builtin_amdgcn_s_barrier();                       // ... everybody's; the other image is no longer being read
     const long k0 = (long)tile * DZ_KT;
-    // this lane's eight 16-byte pieces of Z for the tile's epilogue passes, requested now: they arrive behind the MFMAs (a
-    // load issued inside its pass is a full memory round trip per pass, eight in a row per tile)
-    const int jr = lane >> 2, c8 = lane & 3;           // row of an epilogue patch, which 8 of its 32 columns
-    uint4 zraw[2][4];
+    // this lane's 16-byte pieces of Z for the tile's epilogue passes, requested now: they arrive behind the MFMAs
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 zraw[2][4];
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        const int j = jwave + n * 16 + jr;
-        zraw[half][n] = make_uint4(0u, 0u, 0u, 0u);
-        if (j < Bn) zraw[half][n] = Vec16<E>::load_raw(Z + (size_t)j * row_elems + k0 + half * 32 + c8 * 8);
+        if (n < nv) {                                   // (wave-uniform)
+          const E* zk = Z + k0 + half * 32;             // scalar base of the tile's half; the lane's part is zoff[n]
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zraw[half][n]) : "v"(zoff[n]), "s"(zk) : "memory");
+        }
       }
-    if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, buf ^ 1);
+    const bool more = tile + (int)gridDim.x < ntiles;
+    if (more) stage(tile + gridDim.x, buf ^ 1);
     const unsigned char* img = smem + buf * DZ_YB;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {             // 32 columns k at a time: 8 accumulator fragments
@@ -121,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void clip_dz_kernel(const E* __restrict__ G
       // 16-byte chunks), then lane -> (row j = lane >> 2, 8 consecutive k): 16-byte accesses to Z and dZ
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
+        if (n >= nv) continue;                          // (wave-uniform: no valid column in this block, nothing loaded, nothing stored)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           const int ch = (m * 4 + lq) ^ (lr & 7);      // 16-byte chunk (4 floats) of row lr, swizzled
@@ -128,12 +176,16 @@ __global__ __launch_bounds__(256, 2) void clip_dz_kernel(const E* __restrict__ G
         }
         const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + jr * 32 + (((2 * c8) ^ (jr & 7)) * 4));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + jr * 32 + (((2 * c8 + 1) ^ (jr & 7)) * 4));
+        // the counted wait for this pass's Z piece, tied to the registers it guards (the compiler may not use them above it)
+        wait_later(more);
+        asm volatile("" : "+v"(zraw[half][n]));           // (one 128-bit operand: nothing may read these registers above the wait;
+                                                            //  tools/check_dma_hazard.py audits the listing for a touch in between)
         const int j = jwave + n * 16 + jr;
         if (j < Bn) {
-          const size_t off = (size_t)j * row_elems + k0 + half * 32 + c8 * 8;
-          const float cs = cscale ? cscale[j] : 1.f, rs = rscale[j];
+          const size_t off = (size_t)(zoff[n] / sizeof(E)) + k0 + half * 32;
+          const float cs = csr[n], rs = rsr[n];
           float z[8], v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          Vec16<E>::unpack(zraw[half][n], z);
+          Vec16<E>::unpack(make_uint4(zraw[half][n][0], zraw[half][n][1], zraw[half][n][2], zraw[half][n][3]), z);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = os * (cs * v[e] - rs * z[e]);
           Vec16<E>::store(out + off, v);

@@ -276,6 +276,19 @@ __device__ inline void lds_dma16_sv(const void* sbase_in, uint32_t voff, uint32_
   const void* sbase = (const void*)(uintptr_t)(((uint64_t)sb_hi << 32) | (uint64_t)sb_lo);
   asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the immediate must be a literal); anything above the
+// table waits for everything, which is always safe.
+__device__ inline void wait_vmcnt_dyn(int n) {
+#define SDA_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    SDA_VMC(1) SDA_VMC(2) SDA_VMC(3) SDA_VMC(4) SDA_VMC(5) SDA_VMC(6) SDA_VMC(7) SDA_VMC(8) SDA_VMC(9) SDA_VMC(10)
+    SDA_VMC(11) SDA_VMC(12) SDA_VMC(13) SDA_VMC(14) SDA_VMC(15) SDA_VMC(16) SDA_VMC(17) SDA_VMC(18) SDA_VMC(19)
+    SDA_VMC(20) SDA_VMC(21) SDA_VMC(22) SDA_VMC(23) SDA_VMC(24)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef SDA_VMC
+}
+
 __device__ inline uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const void*)p);
 }

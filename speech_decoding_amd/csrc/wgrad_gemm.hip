@@ -36,19 +36,6 @@ template <> struct WK<uint16_t> { static constexpr int KSTEP = 32; };
 template <> struct WK<half_t> { static constexpr int KSTEP = 32; };
 template <> struct WK<float> { static constexpr int KSTEP = 16; };
 
-// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the immediate must be a literal); anything above the
-// table waits for everything, which is always safe.
-__device__ inline void wait_vmcnt_dyn(int n) {
-#define SDA_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    SDA_VMC(1) SDA_VMC(2) SDA_VMC(3) SDA_VMC(4) SDA_VMC(5) SDA_VMC(6) SDA_VMC(7) SDA_VMC(8) SDA_VMC(9) SDA_VMC(10)
-    SDA_VMC(11) SDA_VMC(12) SDA_VMC(13) SDA_VMC(14) SDA_VMC(15) SDA_VMC(16) SDA_VMC(17) SDA_VMC(18) SDA_VMC(19)
-    SDA_VMC(20) SDA_VMC(21) SDA_VMC(22) SDA_VMC(23) SDA_VMC(24)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef SDA_VMC
-}
-
 typedef __attribute__((address_space(1))) const void gmem_cv;
 typedef __attribute__((address_space(3))) void lds_v;
 

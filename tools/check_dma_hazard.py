@@ -27,7 +27,7 @@ def main(path, flt=""):
         if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
             continue
         op = t.split()[0]
-        if op == "global_load_lds_dwordx4":
+        if op.startswith("global_load") and "s[" in t:
             mm = re.search(r"s\[(\d+):(\d+)\]", t)
             if mm:
                 regs = {f"s{mm.group(1)}", f"s{mm.group(2)}"}
@@ -46,6 +46,52 @@ def main(path, flt=""):
                         break
         hist.append(t)
     print(f"{path}: {bad} unpadded VALU -> VMEM scalar-base hazards")
+    bad += early_touch(lines)
+    return bad
+
+
+def early_touch(lines):
+    """An inline-asm load into VGPRs (global_load_dword* inside ;;#ASMSTART ... ;;#ASMEND) is invisible to hipcc's wait
+    bookkeeping: its destination counts as written when the statement ends.  Nothing may read or write those registers before
+    the next `s_waitcnt vmcnt` — a compiler copy or spill in between moves garbage.  Linear scan in layout order."""
+    bad, inasm, pending = 0, False, []          # pending: (set of vgpr numbers, text)
+    kernel = ""
+    for ln in lines:
+        m = re.match(r"^(_Z\S+):", ln)
+        if m:
+            kernel, pending = m.group(1), []
+            continue
+        t = ln.strip()
+        if "#ASMSTART" in t:
+            inasm = True
+            continue
+        if "#ASMEND" in t:
+            inasm = False
+            continue
+        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+            continue
+        op = t.split()[0]
+        if op == "s_waitcnt" and "vmcnt" in t:
+            pending = []
+            continue
+        if inasm and re.match(r"global_load_dword(x[234])?$", op):
+            mm = re.match(r"\S+\s+v\[(\d+):(\d+)\]", t) or re.match(r"\S+\s+v(\d+),", t)
+            if mm:
+                lo = int(mm.group(1)); hi = int(mm.group(2)) if mm.lastindex and mm.lastindex > 1 else lo
+                pending.append((set(range(lo, hi + 1)), t))
+            continue
+        if pending:
+            regs = set()
+            for a, b in re.findall(r"v\[(\d+):(\d+)\]", t):
+                regs |= set(range(int(a), int(b) + 1))
+            regs |= {int(a) for a in re.findall(r"(?<![\w\[])v(\d+)\b", t)}
+            for dst, txt in pending:
+                if regs & dst:
+                    print(f"EARLY TOUCH in {kernel[:70]}: '{t}' uses the destination of '{txt}' before any vmcnt wait")
+                    bad += 1
+                    pending = [p_ for p_ in pending if p_[1] != txt]
+                    break
+    print(f"  {bad} touches of an asm load's destination before its wait")
     return bad
 
 
