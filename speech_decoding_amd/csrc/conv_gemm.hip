@@ -98,28 +98,11 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
   }
   const int tiles_total = a.B * n_t_tiles;
   const int groups_total = (tiles_total + NT - 1) / NT;
-  int ks = bid / groups_total;
-  int tt = (bid - ks * groups_total) * NT + tsel;   // linear (sample, t-tile) index of this wave's tile
-  if (a.ksplit > 1) {
-    // split-K matrix mode (the loss's similarity matmul: a handful of output tiles, thousands of K slices): ALL output
-    // tiles of one K slice go to the same XCD, side by side in dispatch order — each slice of BOTH operands then leaves
-    // HBM once and is re-read from that XCD's L2 (with the order above the two row tiles of a slice sat on different
-    // XCDs and the column operand was fetched twice: 604 MB for 394 MB of operands, PMC).  Pure speed.
-    const int per_slice = n_co * groups_total, grp = 8 * per_slice;
-    const int full = (int)(gridDim.x / grp) * grp, b0 = (int)blockIdx.x;
-    int j;
-    if (b0 < full) {
-      const int base = b0 / grp * grp, rem = b0 - base;
-      ks = base / per_slice + (rem & 7);
-      j = rem >> 3;
-    } else {
-      const int rem = b0 - full;
-      ks = full / per_slice + rem / per_slice;
-      j = rem % per_slice;
-    }
-    co_tile = j % n_co;
-    tt = (j / n_co) * NT + tsel;
-  }
+  const int ks = bid / groups_total;
+  const int tt = (bid - ks * groups_total) * NT + tsel;   // linear (sample, t-tile) index of this wave's tile
+  // (split-K matrix mode — the loss's similarity matmul — keeps this order: with ALL output tiles of a K slice dealt to one XCD
+  // the column operand is fetched once instead of twice (604 -> ~400 MB) and the kernel alone is 7 % faster, 113 -> 106 us,
+  // but IN THE STEP, where both operands have just been written, it was 14-18 us slower on every box tried — DESIGN.md §7)
   const bool tile_ok = tt < tiles_total;
   const int b = tile_ok ? tt / n_t_tiles : 0;
   const int t_tile = tile_ok ? tt - b * n_t_tiles : 0;

@@ -1,8 +1,8 @@
-# One round's measurement set, run on the GPU box:  bash tools/profile_round.sh r03
+# One round's measurement set, run on the GPU box:  bash tools/profile_round.sh r04
 # (clean bench line, the same command under rocprofv3 --kernel-trace --stats, the two PMC passes behind roofline.traffic,
 #  the fp32 line; the summaries worth keeping are copied from gpurun_out/<tag>/ into profiles/ by hand)
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
@@ -19,3 +19,8 @@ cd $R
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_summary.json | head -8
 python tools/timeline.py $O/trace/tr_kernel_trace.csv > $O/step_timeline.txt
 head -6 $O/step_timeline.txt
+# round 4 additions: SQ counters of the step per kernel (MFMA utilisation, SALU / VALU per MFMA), collate throughput
+bash tools/pmc_step_sq.sh $TAG > /dev/null 2>&1 || true
+head -12 $O/step_sq_counters.txt
+timeout -k 10 120 python tools/bench_collate.py > $O/bench_collate.txt 2>&1 || true
+cat $O/bench_collate.txt | grep -v amdgpu.ids
