@@ -223,6 +223,10 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
     if (c_valid == KT && xrow0 >= 0 && xrow0 + KT + 2 * halo <= a.rows_limit) {
       dy_base = dyg + (size_t)c_row * a.dy_pitch + co0;
       x_base = xg + (size_t)xrow0 * a.x_pitch + ci0;
+#ifdef SDA_WGRAD_FAKE_SRC      /* diagnostic build (garbage results): every chunk re-reads the segment's first rows — no memory-system load */
+      dy_base = dyg + (size_t)seg_r0 * a.dy_pitch + co0;
+      x_base = xg + (size_t)seg_r0 * a.x_pitch + ci0;
+#endif
       nxt_off = (uint32_t)(buf * G::STAGE);
       return true;
     }
@@ -241,7 +245,12 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
   };
   constexpr int NPW = NDY + NX;                // pieces per wave and chunk (upper bound)
   constexpr int NGRP = (KT / KSTEP) * KS;      // MFMA groups per chunk
-  constexpr int PER_GRP = (NPW + NGRP - 1) / NGRP;
+#ifndef SDA_WGRAD_FRONT
+#define SDA_WGRAD_FRONT 1
+#endif
+  // pieces per MFMA group: SDA_WGRAD_FRONT = 1 spreads them over all groups of the chunk, 2 over its first half, 3 over its
+  // first third (more time to land before the next chunk's wait; an issue is three scalar-side instructions now)
+  constexpr int PER_GRP = (NPW * SDA_WGRAD_FRONT + NGRP - 1) / NGRP;
 
   // 16-bit types: per-lane offsets of every transposed fragment read of a stage, computed once (tr_operand.h); a read of
   // K-step kk is then `stage base + offset` plus the immediate kk * KSTEP rows
@@ -265,31 +274,57 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
     const unsigned char* dys = smem + cur * G::STAGE;
     cur ^= 1;
     const unsigned char* xs = dys + G::DY_BYTES;
-    wg_static_for<0, KT / KSTEP>([&](auto kc) {
+    // MFMA groups g = (kk, tap) of the chunk, software-pipelined IN THE SOURCE: group g + 1's x fragments (and, on a K-step's
+    // last tap, the next K-step's dy fragments) are read BEFORE group g's MFMAs.  hipcc cannot do this itself — the LDS-DMA
+    // asm statements between the groups are memory barriers to it — and without it every group began with its own fragment
+    // reads and a full wait for them: six exposed LDS round trips per chunk on a SIMD that holds one wave of this kernel.
+    constexpr int NKK = KT / KSTEP, NG = NKK * KS;
+    auto read_a = [&](auto kc, uint4 (&af)[MREP]) {
       constexpr int kk = decltype(kc)::value;
-      uint4 af[MREP];
 #pragma unroll
       for (int m = 0; m < MREP; ++m) {
         if constexpr (FASTTR) af[m] = tr_read_bf16<G::RB_M>(dys + a_off[m] + kk * KSTEP * G::RB_M);
         else af[m] = TrOp<E, G::RB_M>::get(dys, kk * KSTEP, wave_m * (TILE_M / 2) + m * 16, lane);
       }
-      wg_static_for<0, KS>([&](auto tc) {
-        constexpr int tap = decltype(tc)::value;
-        uint4 bf[NREP];
+    };
+    auto read_b = [&](auto gc, uint4 (&bf)[NREP]) {
+      constexpr int g = decltype(gc)::value, kk = g / KS, tap = g % KS;
 #pragma unroll
-        for (int n = 0; n < NREP; ++n) {
-          if constexpr (FASTTR) bf[n] = tr_read_bf16<G::RB_N>(dys + b_off[tap][n] + kk * KSTEP * G::RB_N);
-          else bf[n] = TrOp<E, G::RB_N>::get(xs, kk * KSTEP + tap * a.dil, wave_n * (TN / 2) + n * 16, lane);
-        }
+      for (int n = 0; n < NREP; ++n) {
+        if constexpr (FASTTR) bf[n] = tr_read_bf16<G::RB_N>(dys + b_off[tap][n] + kk * KSTEP * G::RB_N);
+        else bf[n] = TrOp<E, G::RB_N>::get(xs, kk * KSTEP + tap * a.dil, wave_n * (TN / 2) + n * 16, lane);
+      }
+    };
+    // (kernel size 3 only: the 1 x 1 instantiations have no registers for a second fragment set — <160, 1, 128> would
+    // drop to one wave per SIMD — and read each group's fragments at its start, as before)
+    constexpr bool PIPE = KS == 3;
+    uint4 af[MREP], bf[NREP];
+    read_a(std::integral_constant<int, 0>{}, af);
+    read_b(std::integral_constant<int, 0>{}, bf);
+    wg_static_for<0, NG>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, kk = g / KS, tap = g % KS;
+      uint4 af_n[MREP], bf_n[NREP];
+      if constexpr (!PIPE && g > 0) {
+        if constexpr (tap == 0) read_a(std::integral_constant<int, kk>{}, af);
+        read_b(gc, bf);
+      }
+      if constexpr (PIPE && g + 1 < NG) read_b(std::integral_constant<int, g + 1>{}, bf_n);
+      if constexpr (PIPE && tap == KS - 1 && kk + 1 < NKK) read_a(std::integral_constant<int, kk + 1>{}, af_n);
 #pragma unroll
-        for (int m = 0; m < MREP; ++m)
+      for (int m = 0; m < MREP; ++m)
 #pragma unroll
-          for (int n = 0; n < NREP; ++n) acc[tap][m][n] = mma16<E>(af[m], bf[n], acc[tap][m][n]);
-        if (fast) {
-          constexpr int grp = kk * KS + tap;
-          wg_static_for<grp * PER_GRP, (grp + 1) * PER_GRP < NPW ? (grp + 1) * PER_GRP : NPW>(issue_piece);
-        }
-      });
+        for (int n = 0; n < NREP; ++n) acc[tap][m][n] = mma16<E>(af[m], bf[n], acc[tap][m][n]);
+      if (fast) {
+        wg_static_for<g * PER_GRP, (g + 1) * PER_GRP < NPW ? (g + 1) * PER_GRP : NPW>(issue_piece);
+      }
+      if constexpr (PIPE && g + 1 < NG) {
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bf[n] = bf_n[n];
+      }
+      if constexpr (PIPE && tap == KS - 1 && kk + 1 < NKK) {
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) af[m] = af_n[m];
+      }
     });
   }
 

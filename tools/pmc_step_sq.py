@@ -19,7 +19,7 @@ rows = []
 for k, c in acc.items():
     if "sda" not in k:
         continue
-    g = lambda n: c[n][0] if n in c else 0.0
+    g = lambda n, c=c: c[n][0] if n in c else 0.0
     n = max(v[1] for v in c.values())
     rows.append((g("SQ_BUSY_CYCLES"), short(k), n, g, ))
 rows.sort(reverse=True)
