@@ -97,8 +97,10 @@ class EncoderEngine:
         self.forward_pair_tiles = True       # forward k = 3 convs (nothing competes for the CU's LDS there): two
                                              # tiles per workgroup share each weight slab — fewer LDS-DMA bytes per FLOP
         self.flat_tiles_forward = True       # k = 3 convs on the 256-row flat-tile kernel (conv3_flat.hip) where it applies
-        self.flat_tile_options = 0           # extra conv3_flat flags: 1024 = co-resident workgroups take their tiles in opposite
-                                             # order, 64 = static priority for one workgroup of each pair
+        self.flat_tile_options = 1024        # extra conv3_flat flags: 1024 = the second workgroup of a CU takes its 128-row tile FIRST
+                                             # (the pair's epilogues — HBM bursts with the matrix pipe idle — fall at different
+                                             # times: 68.6 -> 67.3 us per 320 -> 320 conv with the priority hand-over, round 4),
+                                             # 64 = no priority hand-over between the two (diagnostic)
         self.fuse_glu_forward = True         # F.glu in conv2's epilogue (flat-tile kernel, D2p % 80 == 0): no [value | gate] buffer
         self.bias_sums_on_side = True        # final reduction of the bias-gradient column sums on the weight-gradient stream
         self.fuse_glu_backward = False       # the GLU backward in the epilogue of the conv that produces its incoming gradient
