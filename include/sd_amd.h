@@ -52,9 +52,25 @@ enum { SDA_EPI_GELU = 1,
        SDA_CONV_SINGLE_TILE = 4096, /* force one 128-row tile per workgroup */
        SDA_CONV_PAIR_TILES = 8192,  /* two tiles per workgroup sharing one weight slab (default: one) */
        SDA_CONV_ONE_PER_CU = 32768, /* with SDA_CONV_FLAT_TILES: at most one workgroup per CU (half the LDS stays free) */
-       SDA_CONV_FLAT_TILES = 16384  /* kernel size 3 with Cout_p % 160 == 0: 256-row x 160-channel tiles cut from the
-                                       flat row space, two workgroups per CU (conv3_flat.hip); other shapes ignore the
-                                       flag.  `stats` then has sda_conv_stats_rows(...) rows instead of B * n_t_tiles */ };
+       SDA_CONV_FLAT_TILES = 16384, /* kernel size 3 with Cout_p % 160 == 0: 256-row x 160-channel tiles cut from the
+                                       flat row space, two workgroups per CU (conv3_flat.hip); kernel size 1 with
+                                       Cout_p % 160 == 0 or Cout_p % 128 == 0, shared weights, no residual / statistics:
+                                       the same tiling (conv1_flat.hip); other shapes ignore the flag.  `stats` then has
+                                       sda_conv_stats_rows(...) rows instead of B * n_t_tiles */
+       /* two epilogues of the flat kernel-size-1 form only (SDA_CONV_FLAT_TILES must be set, else the call fails): */
+       SDA_EPI_GELU_BWD = 65536,    /* the conv's output is the gradient entering a GELU whose input u = bn_x ([rows][Cout_p],
+                                       same layout as y) the forward kept: y = round(conv) * GELU'(u) (what sda_gelu_backward_colsum
+                                       computes from the stored gradient), `stats` rows (sda_conv_stats_rows) = per-unit column
+                                       sums of the products in plane 0 (the bias gradient of the layer that fed the GELU), plane 1
+                                       zero.  No bias / y_pre / SDA_EPI_GELU */
+       SDA_EPI_BN_STORE_DG = 262144,/* with bn_x (the BatchNorm-backward statistics epilogue): y = dg = round(dy) * GELU'(gamma * xhat + beta),
+                                       rounded to the storage type, INSTEAD of dy, and the statistics are those of dg as stored —
+                                       sda_bn_gelu_backward_from_stats_dg / _apply_dg then finish the BatchNorm backward without
+                                       evaluating GELU' a second time */
+       SDA_EPI_ROW_SUMSQ = 131072   /* Cout_p % 128 == 0: `stats` = float [>= B * (T + SDA_ROW_PAD) rows][Cout_p / 128]; entry
+                                       [r][j] = sum of squares of buffer row r's output channels [128 j, 128 j + 128) as stored
+                                       (rows that are padding are not written); sda_rows_sumsq_from_row_parts turns them into
+                                       per-sample norms */ };
 
 int sda_abi_version(void);
 const char* sda_last_error(void);
@@ -78,6 +94,9 @@ int sda_rows_sumsq(const void* x, float* out, float* scratch, int B, long row_el
 /* the same norms for a tensor a conv just produced, from that conv's per-tile statistics ([B * tiles_per_sample][2][Cp],
  * plane 1 = sum of squares of the stored values): no second pass over the tensor */
 int sda_rows_sumsq_from_stats(const float* stats, int tiles_per_sample, int Cp, float* out, int B, void* stream);
+/* the same from SDA_EPI_ROW_SUMSQ's per-row partial sums ([rows][n_parts]): out[b] = sum over sample b's T rows and
+ * n_parts entries, fp64, fixed order */
+int sda_rows_sumsq_from_row_parts(const float* parts, int n_parts, float* out, int B, int T, void* stream);
 
 /* fp32 conv weight [nW][Cout][Cin][KS]  ->  packed `dtype` operand.
  * mode 0 (forward):  dst[n][tap][co'][ci]  = w[n][co][ci][tap]
@@ -192,6 +211,17 @@ int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean,
                                const float* gamma, const float* beta, int C, const float* dgamma,
                                const float* dbeta, double count, float* coef /* 6*Cp floats scratch */, void* dx,
                                int B, int T, int Cp, int dtype, void* stream);
+/* the same two for a gradient buffer that already holds dg = dy * GELU'(gamma * xhat + beta) (written by sda_conv_gemm with
+ * SDA_EPI_BN_STORE_DG, whose statistics rows are those of dg as stored): no second GELU' evaluation */
+int sda_bn_gelu_backward_from_stats_dg(const float* partial, int nrows, const void* dy, const void* x, const float* mean,
+                                    const float* rstd, const float* gamma, const float* beta, int C, double count,
+                                    float* dgamma, float* dbeta, float* coef, void* dx, int B, int T, int Cp, int dtype,
+                                    void* stream);
+int sda_bn_gelu_backward_apply_dg(const void* dy, const void* x, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int C, const float* dgamma,
+                               const float* dbeta, double count, float* coef /* 6*Cp floats scratch */, void* dx,
+                               int B, int T, int Cp, int dtype, void* stream);
+
 int sda_reduce_scratch_floats(int Cp);
 
 /* Zero the rows of an RL buffer that kernels never write: the SDA_ROW_PAD rows in front of each of the B samples and the

@@ -23,22 +23,11 @@
 //     workgroups that share a CU take their tiles in a different order (128 first / 128 last), so they reach their
 //     epilogues at different times: one's HBM traffic runs under the other's MFMAs instead of both idling the matrix
 //     cores together, and the work divides evenly whatever the shape (no partly filled last round).
-#include "conv_tile.h"
-
-#include <type_traits>
-#include <utility>
+#include "flat_tile.h"
 
 namespace sda {
 
 namespace {
-
-// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
-template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
 
 constexpr int F_UNIT = 128;                          // rows per work unit
 constexpr int F_CO = 160;                            // output channels per workgroup
@@ -95,32 +84,6 @@ template <int MREP> struct FSched {
   // tap 0 (0)) are behind everything but that stream's groups 1 and 2
   static constexpr int WAITP = G1 + G2;
 };
-
-template <int N> __device__ __forceinline__ void wait_vmcnt_lit() {
-  static_assert(N >= 0 && N <= 8, "add the literal");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-}
-
-// One LDS-DMA piece, lean form: wave-uniform 64-bit source base (an SGPR pair the caller computed with scalar arithmetic
-// well ahead — no VALU-written SGPR feeds the load, so no s_nop 4), ONE per-lane byte offset register, and M0 written in
-// the statement that reads it (nothing else in these kernels keeps a value in M0, so it is not saved).
-// PADDED = true opens with s_nop 4: for the places (a tile's prologue) where hipcc may hand the statement a scalar it has
-// just reloaded from a spill lane (v_readlane: a VALU write).  tools/check_dma_hazard.py walks the listing for unpadded ones.
-template <bool PADDED = false>
-__device__ __forceinline__ void lds_dma16_lean(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  if constexpr (PADDED)
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-  else
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
 
 // MFMA "weights" fragment of a 16-column identity block: B[col][k] = 1 where k == 16 * half + col, as mma16<E> reads
 // it (lane (lr = col, lq) holds k = 8 lq + j in element j; fp32: k = 4 lq + j, one 16-wide block per slab, half = 0).
@@ -235,8 +198,6 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
     else if constexpr (jhi >= b1) lds_dma16_lean<PD>(pbase[i], kvoff, j < b1 ? xdst + (uint32_t)cx : wdst1 + (uint32_t)c1);
     else lds_dma16_lean<PD>(pbase[i], kvoff, xdst + (uint32_t)cx);
   };
-  using TrueC = std::integral_constant<bool, true>;
-  using FalseC = std::integral_constant<bool, false>;
 
   const int nslab = (a.flags & 512) ? 1 : c.nslab;          // flag 512 (diagnostic): one K-step only — the epilogue's time (results are garbage)
   // ---- tile prologue: tap 0 of K-step 0, then the stream of "K-step -1" (x(0), taps 1 and 2 of K-step 0, tap 0 of K-step 1)
@@ -493,21 +454,28 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
 #pragma unroll
             for (int j = 0; j < CH; ++j) v[j] += r8[j];
           }
-          Vec16<E>::store(yg + row_off(it), v);
           if constexpr (BN) {
             // BatchNorm+GELU backward sums of the layer this gradient enters: dg = dy * GELU'(gamma * xhat + beta), dy as stored
+            // (SDA_EPI_BN_STORE_DG: dg is what gets stored, and summed as stored)
+            const bool store_dg = a.flags & SDA_EPI_BN_STORE_DG;
+            if (!store_dg) Vec16<E>::store(yg + row_off(it), v);
             float x8[CH];
             Vec16<E>::unpack(bx_cur, x8);
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-              const float dg = Vec16<E>::round(v[j]) * gelu_grad_f<E>(fmaf(ca[j], x8[j], cb[j]));
+              float dg = Vec16<E>::round(v[j]) * gelu_grad_f<E>(fmaf(ca[j], x8[j], cb[j]));
+              if (store_dg) { dg = Vec16<E>::round(dg); v[j] = dg; }
               ssum[j] += dg;
               ssq[j] = fmaf(dg, x8[j], ssq[j]);
             }
+            if (store_dg) Vec16<E>::store(yg + row_off(it), v);
           } else if (a.stats) {
+            Vec16<E>::store(yg + row_off(it), v);
             // statistics of the values as stored (rounded to E), so BatchNorm normalises what it will read
 #pragma unroll
             for (int j = 0; j < CH; ++j) { const float qv = Vec16<E>::round(v[j]); ssum[j] += qv; ssq[j] += qv * qv; }
+          } else {
+            Vec16<E>::store(yg + row_off(it), v);
           }
         }
         ok_cur = ok_nxt; bx_cur = bx_nxt; rv_cur = rv_nxt;
@@ -698,5 +666,6 @@ int launch_conv3_flat(const sda_conv_args& a, hipStream_t st) {
 // (one per 128-row tile of a sample), the flat-tile kernel one per 128-row unit of the flat row space
 extern "C" int sda_conv_stats_rows(int B, int T, int KS, int Cout_p, int flags) {
   if ((flags & SDA_CONV_FLAT_TILES) && KS == 3 && Cout_p % sda::F_CO == 0) return sda::conv3_flat_stat_rows(B, T);
+  if ((flags & SDA_CONV_FLAT_TILES) && KS == 1 && (flags & SDA_EPI_GELU_BWD)) return sda::conv3_flat_stat_rows(B, T);   // conv1_flat: same units
   return B * ((T + sda::TILE_T - 1) / sda::TILE_T);
 }

@@ -35,7 +35,11 @@ template <int TILE_CO, int KS, int NT> constexpr int conv_stage_bytes() { return
 // (measured, config-2 shapes alone: the similarity matmul 203 -> 114 us at 256 x 256 samples, 710 -> 631 us at 2048 x 256;
 // the row-layout 1x1 convs, whose time is their epilogue's, gained nothing and lose co-residency: they keep two stages)
 template <int TILE_CO, int NT, int KS, bool SV> constexpr int conv_stages() {
+#ifdef SDA_RING_SV
+  return (NT == 2 && KS == 3) ? 3 : ((NT == 1 && KS == 1) ? (TILE_CO > 128 ? 3 : 4) : 2);
+#else
   return (NT == 2 && KS == 3) ? 3 : ((NT == 1 && KS == 1 && !SV) ? (TILE_CO > 128 ? 3 : 4) : 2);
+#endif
 }
 template <int TILE_CO, int KS, int NT, bool SV = true> constexpr int conv_lds_bytes() {
   constexpr int main_b = conv_stages<TILE_CO, NT, KS, SV>() * conv_stage_bytes<TILE_CO, KS, NT>();
@@ -62,7 +66,9 @@ template <> __device__ inline float4 round_like<uint16_t>(float4 v) {
 // piece starts at a wave-uniform row, so its address is a scalar base + ONE per-lane offset register (lds_dma16_sv) and the
 // per-piece arithmetic runs on the scalar unit — with per-lane 64-bit addresses the staging cost ~100 VALU instructions
 // per K-step and wave, a third of the MFMA time beside it.
-template <typename E, int TILE_CO, int KS, int NT, bool BN = false, bool SV = true>
+// BN: 0 = off, 1 = BatchNorm-backward statistics epilogue (bn_x), 2 = the same storing dg instead of dy (SDA_EPI_BN_STORE_DG;
+// a template parameter, not a branch: with both forms in one kernel the code grew by 15 % and the step by 0.13 ms)
+template <typename E, int TILE_CO, int KS, int NT, int BN = 0, bool SV = true>
 __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_args a, const int n_t_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SLAB = ROW_B / (int)sizeof(E);          // input channels per LDS row / K-step
@@ -221,7 +227,12 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
     }
   };
 
-  if constexpr (KS == 1 && NT == 1 && !SV) {
+#ifdef SDA_RING_SV
+  constexpr bool RING = KS == 1 && NT == 1;
+#else
+  constexpr bool RING = KS == 1 && NT == 1 && !SV;
+#endif
+  if constexpr (RING) {
     // Ring of NS stages, D = NS - 1 slabs of LDS-DMA in flight.  Every wave issues EXACTLY PPW pieces per slab (2 input + 2 or 3
     // weight pieces; indices past the end are clamped, duplicates rewrite identical bytes), so a counted s_waitcnt retires slab
     // s while its successors stay in flight across the raw s_barrier.  Slab s + D goes into the buffer slab s - 1 was read
@@ -515,23 +526,31 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
               continue;
             }
           }
-          Vec16<E>::store(yg + off, v);
           if constexpr (BN) {
             // BatchNorm+GELU backward sums of the layer this gradient enters (what col_reduce_kernel<E, 1>
-            // computes in a pass of its own): dg = dy * GELU'(gamma * xhat + beta) with dy as stored
+            // computes in a pass of its own): dg = dy * GELU'(gamma * xhat + beta) with dy as stored.
+            // SDA_EPI_BN_STORE_DG: dg itself is what gets stored (and summed as stored) — the pass that finishes the
+            // BatchNorm backward then needs no GELU' of its own
+            constexpr bool store_dg = BN == 2;
+            if (!store_dg) Vec16<E>::store(yg + off, v);
             float x8[CH];
             Vec16<E>::unpack(bx[it], x8);
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
               const float xh = (x8[j] - bmu[j]) * brs[j];
-              const float dg = Vec16<E>::round(v[j]) * gelu_grad_f<E>(bga[j] * xh + bbe[j]);
+              float dg = Vec16<E>::round(v[j]) * gelu_grad_f<E>(bga[j] * xh + bbe[j]);
+              if (store_dg) { dg = Vec16<E>::round(dg); v[j] = dg; }
               ssum[j] += dg;
               ssq[j] += dg * xh;
             }
+            if (store_dg) Vec16<E>::store(yg + off, v);
           } else if (a.stats) {
+            Vec16<E>::store(yg + off, v);
             // statistics of the values as stored (rounded to E), so BN normalises what it will read
 #pragma unroll
             for (int j = 0; j < CH; ++j) { const float q = Vec16<E>::round(v[j]); ssum[j] += q; ssq[j] += q * q; }
+          } else {
+            Vec16<E>::store(yg + off, v);
           }
         }
       }
@@ -558,7 +577,7 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
   }
 }
 
-template <typename E, int TILE_CO, int KS, int NT, bool BN = false, bool SV = true>
+template <typename E, int TILE_CO, int KS, int NT, int BN = 0, bool SV = true>
 static int launch_conv(const sda_conv_args& a, hipStream_t st) {
   constexpr int lds = conv_lds_bytes<TILE_CO, KS, NT, SV>();
   static unsigned long long attr_done = 0;        // per device
@@ -597,9 +616,10 @@ static int dispatch_conv_nt(const sda_conv_args& a, hipStream_t st) {
                   (long)a.x_pitch * 16 * (long)sizeof(E) < (1L << 31) && (long)a.w_pitch * 16 * (long)sizeof(E) < (1L << 31);
   if (!sv) {
     if (k3 || pair) { set_error("conv_gemm: kernel-3 / paired-tile launches need row-layout operands"); return -1; }
-    return launch_conv<E, TILE_CO, 1, 1, false, false>(a, st);
+    return launch_conv<E, TILE_CO, 1, 1, 0, false>(a, st);
   }
-  if (a.bn_x) return pair ? launch_conv<E, TILE_CO, 3, 2, true>(a, st) : launch_conv<E, TILE_CO, 3, 1, true>(a, st);
+  if (a.bn_x && (a.flags & SDA_EPI_BN_STORE_DG)) return pair ? launch_conv<E, TILE_CO, 3, 2, 2>(a, st) : launch_conv<E, TILE_CO, 3, 1, 2>(a, st);
+  if (a.bn_x) return pair ? launch_conv<E, TILE_CO, 3, 2, 1>(a, st) : launch_conv<E, TILE_CO, 3, 1, 1>(a, st);
   if (pair) return k3 ? launch_conv<E, TILE_CO, 3, 2>(a, st) : launch_conv<E, TILE_CO, 1, 2>(a, st);
   return k3 ? launch_conv<E, TILE_CO, 3, 1>(a, st) : launch_conv<E, TILE_CO, 1, 1>(a, st);
 }
@@ -610,6 +630,11 @@ static int dispatch_conv(const sda_conv_args& a, hipStream_t st) {
     // (exactly the condition sda_conv_stats_rows uses: the statistics rows a caller sized must be the rows written)
     if (!conv3_flat_supports(a)) { set_error("conv_gemm: SDA_CONV_FLAT_TILES needs a plain row-layout kernel-3 convolution"); return -1; }
     return launch_conv3_flat(a, st);
+  }
+  if ((a.flags & SDA_CONV_FLAT_TILES) && a.KS == 1 && conv1_flat_supports(a)) return launch_conv1_flat(a, st);
+  if (a.flags & (SDA_EPI_GELU_BWD | SDA_EPI_ROW_SUMSQ)) {
+    set_error("conv_gemm: SDA_EPI_GELU_BWD / SDA_EPI_ROW_SUMSQ need SDA_CONV_FLAT_TILES and a plain row-layout kernel-1 convolution");
+    return -1;
   }
   if (a.flags & SDA_EPI_GLU) { set_error("conv_gemm: SDA_EPI_GLU needs SDA_CONV_FLAT_TILES, kernel size 3 and Cout_p % 160 == 0"); return -1; }
   // 1x1 convs whose width divides both ways (640): 128-channel tiles (conv_final1 forward 125 -> 113 us, conv_final2's data
@@ -642,7 +667,7 @@ extern "C" int sda_conv_gemm(const sda_conv_args* a, void* stream) {
                                      (a->flags & (SDA_EPI_GELU | SDA_EPI_GLU | SDA_CONV_FLAT_TILES)))) {
     set_error("conv_gemm: SDA_EPI_GLU_BWD needs glu_out, glu_gate and stats, and excludes bn_x / GELU / flat tiles / split-K"); return -1;
   }
-  if (a->bn_x && (!a->bn_coef || !a->stats || a->partial || (a->flags & SDA_EPI_GELU))) {
+  if (a->bn_x && !(a->flags & SDA_EPI_GELU_BWD) && (!a->bn_coef || !a->stats || a->partial || (a->flags & SDA_EPI_GELU))) {
     set_error("conv_gemm: bn_x needs bn_coef and stats, and excludes split-K / GELU epilogues"); return -1;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -22,4 +22,8 @@ int launch_conv3_flat(const sda_conv_args& a, hipStream_t st);
 bool conv3_flat_supports(const sda_conv_args& a);
 int conv3_flat_stat_rows(int B, int T);
 
+// conv1_flat.hip
+int launch_conv1_flat(const sda_conv_args& a, hipStream_t st);
+bool conv1_flat_supports(const sda_conv_args& a);
+
 }  // namespace sda

@@ -195,6 +195,23 @@ __global__ __launch_bounds__(256) void rows_sumsq_from_stats_kernel(const float*
   if (threadIdx.x == 0) out[b] = (float)sh[0];
 }
 
+// per-sample norms from conv1_flat's SDA_EPI_ROW_SUMSQ partials ([buffer row][n_parts]): sample b = rows b * (T + PAD) + PAD + t
+__global__ __launch_bounds__(256) void rows_sumsq_from_row_parts_kernel(const float* __restrict__ parts, int n_parts, int T,
+                                                                        float* __restrict__ out) {
+  __shared__ double sh[256];
+  const int b = blockIdx.x;
+  const float* p = parts + ((size_t)b * rows_tp(T) + PAD) * n_parts;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < T * n_parts; i += 256) s += (double)p[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {                      // fixed tree: deterministic
+    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[b] = (float)sh[0];
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight / vector packing
 // ------------------------------------------------------------------------------------------------
@@ -632,7 +649,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_coef_kernel(const float* __r
   coef[5 * Cp + c] = dg * inv_count;
 }
 
-template <typename E>
+// DG: `dy` already holds dg = dy * GELU'(gamma * xhat + beta) (a conv epilogue with SDA_EPI_BN_STORE_DG wrote it): the affine
+// part only — 5 vector instructions per element pair instead of ~25
+template <typename E, bool DG = false>
 __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restrict__ dy, const E* __restrict__ x,
                                                                 const float* __restrict__ coef, E* __restrict__ dx,
                                                                 int B, int T, int Cp) {
@@ -659,7 +678,8 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restr
 #pragma unroll
       for (int j = 0; j < CH; j += 2) {
         const f32x2 xx = {xv[j], xv[j + 1]}, a2 = {ca[j], ca[j + 1]};
-        const f32x2 g = f32x2{d[j], d[j + 1]} * gelu_grad_pair<E>(fma2(a2, xx, f32x2{cb[j], cb[j + 1]}));
+        f32x2 g = f32x2{d[j], d[j + 1]};
+        if constexpr (!DG) g = g * gelu_grad_pair<E>(fma2(a2, xx, f32x2{cb[j], cb[j + 1]}));
         const f32x2 o = fma2(a2, g, -fma2(f32x2{cq[j], cq[j + 1]}, xx, f32x2{cp[j], cp[j + 1]}));
         d[j] = o.x; d[j + 1] = o.y;
       }
@@ -888,6 +908,12 @@ extern "C" int sda_rows_sumsq_from_stats(const float* stats, int tiles_per_sampl
   return check_launch("rows_sumsq_from_stats");
 }
 
+extern "C" int sda_rows_sumsq_from_row_parts(const float* parts, int n_parts, float* out, int B, int T, void* stream) {
+  if (!parts || !out || n_parts < 1 || B < 1 || T < 1) { set_error("rows_sumsq_from_row_parts: bad arguments"); return -1; }
+  hipLaunchKernelGGL(rows_sumsq_from_row_parts_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, parts, n_parts, T, out);
+  return check_launch("rows_sumsq_from_row_parts");
+}
+
 extern "C" int sda_rows_sumsq(const void* x, float* out, float* scratch, int B, long row_elems, long pitch,
                               int dtype, void* stream) {
   if (!x || !out || !scratch || row_elems % 4 || pitch % 4 || B < 1) { set_error("rows_sumsq: bad arguments"); return -1; }
@@ -1040,10 +1066,10 @@ extern "C" int sda_reduce_stats(const float* partial, int nrows, float* out0, fl
   return check_launch("reduce_stats");
 }
 
-extern "C" int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean, const float* rstd,
-                                          const float* gamma, const float* beta, int C, const float* dgamma,
-                                          const float* dbeta, double count, float* coef, void* dx, int B, int T, int Cp,
-                                          int dtype, void* stream) {
+static int bn_backward_apply(bool dg, const void* dy, const void* x, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, int C, const float* dgamma,
+                             const float* dbeta, double count, float* coef, void* dx, int B, int T, int Cp,
+                             int dtype, void* stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !coef || !dx || Cp % 64 || count < 1.0 || !fits_u32(B, T, Cp)) {
     set_error("bn_gelu_backward_apply: bad arguments"); return -1;
   }
@@ -1051,15 +1077,33 @@ extern "C" int sda_bn_gelu_backward_apply(const void* dy, const void* x, const f
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((Cp + 255) / 256), dim3(256), 0, st, mean, rstd, gamma, beta, C, dbeta,
                      dgamma, inv_count, coef, Cp);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, st,
-                                         (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
+  if (dg) {
+    SDA_DISPATCH(dtype, hipLaunchKernelGGL((bn_gelu_bwd_apply_kernel<E, true>), dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, st,
+                                           (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
+  } else {
+    SDA_DISPATCH(dtype, hipLaunchKernelGGL((bn_gelu_bwd_apply_kernel<E, false>), dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, st,
+                                           (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
+  }
   return check_launch("bn_gelu_backward_apply");
 }
 
-extern "C" int sda_bn_gelu_backward_from_stats(const float* partial, int nrows, const void* dy, const void* x,
-                                              const float* mean, const float* rstd, const float* gamma,
-                                              const float* beta, int C, double count, float* dgamma, float* dbeta,
-                                              float* coef, void* dx, int B, int T, int Cp, int dtype, void* stream) {
+extern "C" int sda_bn_gelu_backward_apply(const void* dy, const void* x, const float* mean, const float* rstd,
+                                          const float* gamma, const float* beta, int C, const float* dgamma,
+                                          const float* dbeta, double count, float* coef, void* dx, int B, int T, int Cp,
+                                          int dtype, void* stream) {
+  return bn_backward_apply(false, dy, x, mean, rstd, gamma, beta, C, dgamma, dbeta, count, coef, dx, B, T, Cp, dtype, stream);
+}
+extern "C" int sda_bn_gelu_backward_apply_dg(const void* dg, const void* x, const float* mean, const float* rstd,
+                                             const float* gamma, const float* beta, int C, const float* dgamma,
+                                             const float* dbeta, double count, float* coef, void* dx, int B, int T, int Cp,
+                                             int dtype, void* stream) {
+  return bn_backward_apply(true, dg, x, mean, rstd, gamma, beta, C, dgamma, dbeta, count, coef, dx, B, T, Cp, dtype, stream);
+}
+
+static int bn_backward_from_stats(bool dg, const float* partial, int nrows, const void* dy, const void* x,
+                                  const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, int C, double count, float* dgamma, float* dbeta,
+                                  float* coef, void* dx, int B, int T, int Cp, int dtype, void* stream) {
   if (!partial || nrows < 1 || !dy || !x || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !coef || !dx ||
       Cp % 64 || count < 1.0 || !fits_u32(B, T, Cp)) {
     set_error("bn_gelu_backward_from_stats: bad arguments"); return -1;
@@ -1067,9 +1111,27 @@ extern "C" int sda_bn_gelu_backward_from_stats(const float* partial, int nrows, 
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_stats_coef_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, partial, nrows, mean, rstd, gamma, beta, C,
                      (float)(1.0 / count), dbeta, dgamma, coef, Cp);
-  SDA_DISPATCH(dtype, hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel<E>, dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, st,
-                                         (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
+  if (dg) {
+    SDA_DISPATCH(dtype, hipLaunchKernelGGL((bn_gelu_bwd_apply_kernel<E, true>), dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, st,
+                                           (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
+  } else {
+    SDA_DISPATCH(dtype, hipLaunchKernelGGL((bn_gelu_bwd_apply_kernel<E, false>), dim3(stream_blocks(B, T, Cp / Vec16<E>::N)), dim3(256), 0, st,
+                                           (const E*)dy, (const E*)x, coef, (E*)dx, B, T, Cp));
+  }
   return check_launch("bn_gelu_backward_from_stats");
+}
+
+extern "C" int sda_bn_gelu_backward_from_stats(const float* partial, int nrows, const void* dy, const void* x,
+                                              const float* mean, const float* rstd, const float* gamma,
+                                              const float* beta, int C, double count, float* dgamma, float* dbeta,
+                                              float* coef, void* dx, int B, int T, int Cp, int dtype, void* stream) {
+  return bn_backward_from_stats(false, partial, nrows, dy, x, mean, rstd, gamma, beta, C, count, dgamma, dbeta, coef, dx, B, T, Cp, dtype, stream);
+}
+extern "C" int sda_bn_gelu_backward_from_stats_dg(const float* partial, int nrows, const void* dg, const void* x,
+                                                 const float* mean, const float* rstd, const float* gamma,
+                                                 const float* beta, int C, double count, float* dgamma, float* dbeta,
+                                                 float* coef, void* dx, int B, int T, int Cp, int dtype, void* stream) {
+  return bn_backward_from_stats(true, partial, nrows, dg, x, mean, rstd, gamma, beta, C, count, dgamma, dbeta, coef, dx, B, T, Cp, dtype, stream);
 }
 
 extern "C" int sda_colsum(const void* x, float* out, float* scratch, int B, int T, int Cp, int dtype, void* stream) {

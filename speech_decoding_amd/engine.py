@@ -116,6 +116,17 @@ class EncoderEngine:
         # (measured in the step: +2 %; with one flat workgroup per CU: +7 %)
         self.flat_tiles_backward = False
         self.flat_backward_one_per_cu = False
+        # the 1x1 projections (conv_final1/2) on conv1_flat.hip's 256-row flat tiles: forward (conv_final2 then leaves per-row
+        # partial sums of squares instead of per-tile statistics for ||Z_b||^2), and their data gradients — conv_final2's with
+        # the GELU backward of conv_final1 and its bias-gradient column sums in the epilogue (SDA_EPI_GELU_BWD: no
+        # gelu_backward_colsum pass over the 640-wide gradient)
+        self.bn_backward_store_dg = True     # the data-gradient convs that feed a BatchNorm+GELU backward store dg = dy * GELU'(u) (which
+                                             # their statistics epilogue computes anyway) instead of dy: the pass that applies the
+                                             # BatchNorm backward does not evaluate GELU' again (SDA_EPI_BN_STORE_DG; a SIMD issues
+                                             # MFMA and ordinary vector instructions through one port)
+        self.flat_1x1_forward = False
+        self.flat_1x1_backward = False
+        self.flat_1x1_options = 0            # extra conv1_flat flags (1024 = staggered tile order, 32768 = one workgroup per CU)
         # CU partition for backward (experiment, default off): k > 0 gives the data-gradient chain (the stream backward() is
         # called on hands over to a CU-masked stream) k of the 8 XCDs and the weight-gradient stream the other 8 - k, instead
         # of letting the two streams' workgroups compete for every CU (hipExtStreamCreateWithCUMask)
@@ -424,16 +435,23 @@ class EncoderEngine:
 
         # ---- two 1x1 projections with GELU (models.py:194-195)
         u1, g1 = rows("u1", d.F1p), rows("g1", d.F1p)
+        f_flags = (L.CONV_FLAT_TILES | self.flat_1x1_options) if self.flat_1x1_forward else 0
         ops.conv_gemm(x, pk["f1w"], g1, B=B, T=T, KS=1, dil=0, bias=pk["f1b"], y_pre=u1 if need_grad else None,
-                      gelu=True, alg_dims=(d.D2, d.F1))
+                      gelu=True, alg_dims=(d.D2, d.F1), flags=f_flags)
         # Z is handed to the caller: a FRESH buffer per forward (the reference returns a new tensor each call), so
         # embeddings kept across forwards stay valid; everything else lives in the reused workspace
         u2, Zt = rows("u2", d.Fp), ops.new_rows_uninit(B, T, d.Fp, dt, dev)
-        zstats = torch.empty((B * ops.n_t_tiles(T), 2, d.Fp), dtype=torch.float32, device=dev)
-        ops.conv_gemm(g1, pk["f2w"], Zt, B=B, T=T, KS=1, dil=0, bias=pk["f2b"], y_pre=u2 if need_grad else None,
-                      gelu=True, stats=zstats, alg_dims=(d.F1, d.F))
-        # ||Z_b||^2 for the loss comes out of the epilogue's per-tile sums: no separate pass over Z (loss.py:65)
-        ops.ROW_NORMS.put(Zt, ops.rows_sumsq_from_stats(zstats, B))
+        # ||Z_b||^2 for the loss comes out of the epilogue's sums: no separate pass over Z (loss.py:65)
+        if f_flags and d.Fp % 128 == 0:
+            zparts = torch.empty((B * L.rows_tp(T), d.Fp // 128), dtype=torch.float32, device=dev)
+            ops.conv_gemm(g1, pk["f2w"], Zt, B=B, T=T, KS=1, dil=0, bias=pk["f2b"], y_pre=u2 if need_grad else None,
+                          gelu=True, row_sumsq=zparts, alg_dims=(d.F1, d.F), flags=f_flags)
+            ops.ROW_NORMS.put(Zt, ops.rows_sumsq_from_row_parts(zparts, B, T))
+        else:
+            zstats = torch.empty((B * ops.n_t_tiles(T), 2, d.Fp), dtype=torch.float32, device=dev)
+            ops.conv_gemm(g1, pk["f2w"], Zt, B=B, T=T, KS=1, dil=0, bias=pk["f2b"], y_pre=u2 if need_grad else None,
+                          gelu=True, stats=zstats, alg_dims=(d.F1, d.F))
+            ops.ROW_NORMS.put(Zt, ops.rows_sumsq_from_stats(zstats, B))
         bufs.update(u1=u1, g1=g1, u2=u2, Z=Zt)
         if not need_grad:
             ctx.bufs = {"Z": Zt}
@@ -594,7 +612,8 @@ class EncoderEngine:
                                      alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]), flags=bflags), None
             st = torch.empty((ops.conv_stats_rows(B, T, KS, out.shape[1], bflags), 2, out.shape[1]), dtype=torch.float32, device=dev)
             ops.conv_gemm(dy, ctx.packed_T[key], out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx, stats=st,
-                          bn_x=bn[0], bn_coef=bn[1], alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]), flags=bflags)
+                          bn_x=bn[0], bn_coef=bn[1], alg_dims=(w_fp32.shape[-3], w_fp32.shape[-2]),
+                          flags=bflags | (L.EPI_BN_STORE_DG if self.bn_backward_store_dg else 0))
             return out, st
 
         def bias_grad(cs, C, glu_half=0, glu_half_p=0):
@@ -618,10 +637,19 @@ class EncoderEngine:
 
         du2 = tmp("du2", d.Fp)
         grads["f2b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u2"], dZt, du2, width=d.Fp, then=lambda cs: bias_grad(cs, d.F))
-        dg1, _ = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
-        grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
+        b1_flags = (L.CONV_FLAT_TILES | self.flat_1x1_options) if self.flat_1x1_backward else 0
         du1 = tmp("du1", d.F1p)
-        grads["f1b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u1"], dg1, du1, width=d.F1p, then=lambda cs: bias_grad(cs, d.F1))
+        if b1_flags and (d.F1p % 160 == 0 or d.F1p % 128 == 0):
+            # conv_final2's data gradient with conv_final1's GELU backward in its epilogue: du1 directly, plus per-unit column sums
+            gst = torch.empty((ops.conv_stats_rows(B, T, 1, d.F1p, b1_flags | L.EPI_GELU_BWD), 2, d.F1p), dtype=torch.float32, device=dev)
+            ops.conv_gemm(du2, ctx.packed_T["f2w"], du1, B=B, T=T, KS=1, dil=0, gelu_bwd_u=bufs["u1"], stats=gst,
+                          alg_dims=(d.F, d.F1), flags=b1_flags)
+            grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
+            grads["f1b"] = on_side(lambda: bias_grad(ops.reduce_stats(gst)[:d.F1p], d.F1))
+        else:
+            dg1, _ = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
+            grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
+            grads["f1b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u1"], dg1, du1, width=d.F1p, then=lambda cs: bias_grad(cs, d.F1))
         # Where the forward kept (out, gate) of every F.glu, the conv that produces the gradient entering a block's GLU (this
         # 1x1 data gradient for block 4, conv0's data gradient of block k + 1 for block k) applies the GLU backward in its
         # epilogue: `glu_pending` = (dc2, per-tile column sums) for the block about to be processed, and dx is never stored
@@ -631,7 +659,10 @@ class EncoderEngine:
             glu_pending = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dc2.4", 2 * d.D2p), 1, 0, glu_bwd=(bufs["x5"], bufs["b4.g"]))
             dx = None
         else:
-            dx, _ = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
+            if b1_flags:
+                dx = ops.conv_gemm(du1, ctx.packed_T["f1w"], tmp("dxA", d.D2p), B=B, T=T, KS=1, dil=0, alg_dims=(d.F1, d.D2), flags=b1_flags)
+            else:
+                dx, _ = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
         grads["f1w"] = wgrad(du1, bufs["x5"], 1, 0, d.F1, d.D2)
         flush(["f2w", "f2b", "f1w", "f1b"])
 
@@ -672,7 +703,8 @@ class EncoderEngine:
                 sync = self.group is not None and ctx.training
                 dgam, dbet = ops.bn_gelu_backward(da1, bufs[f"b{k}.h{j}"], mean, rstd, P[bnp + "w"], P[bnp + "b"], dh, B, T,
                                                   scratch, count=float(B) * T * world if ctx.training else float("inf"),
-                                                  allreduce=self._allreduce if sync else None, tile_stats=tstats)
+                                                  allreduce=self._allreduce if sync else None, tile_stats=tstats,
+                                                  dy_is_dg=bool(self.bn_backward_store_dg and tstats is not None))
                 # under DP the sums are already global on every rank; the gradient all-reduce (SUM) follows
                 if sync:
                     dgam, dbet = dgam / world, dbet / world

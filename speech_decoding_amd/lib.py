@@ -16,6 +16,7 @@ F32, BF16, F16 = 0, 1, 2
 ROW_PAD = 16
 CH_ALIGN = 64
 EPI_GELU, EPI_GLU, EPI_GLU_BWD = 1, 2, 4
+EPI_GELU_BWD, EPI_ROW_SUMSQ, EPI_BN_STORE_DG = 65536, 131072, 262144          # epilogues of conv1_flat only (need CONV_FLAT_TILES)
 CONV_SINGLE_TILE, CONV_PAIR_TILES, CONV_FLAT_TILES, CONV_ONE_PER_CU = 4096, 8192, 16384, 32768
 WGRAD_FLAT_ROWS = 1
 
@@ -69,6 +70,7 @@ SIGNATURES = {
     "sda_unpack_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sda_rows_sumsq": (i32, [vp, vp, vp, i32, i64, i64, i32, vp]),
     "sda_rows_sumsq_from_stats": (i32, [vp, i32, i32, vp, i32, vp]),
+    "sda_rows_sumsq_from_row_parts": (i32, [vp, i32, vp, i32, i32, vp]),
     "sda_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "sda_adam_multi": (i32, [vp, i32, i64, f32, f32, f32, f32, i64, vp]),
     "sda_pack_multi": (i32, [vp, i32, i64, i32, vp]),
@@ -82,9 +84,11 @@ SIGNATURES = {
     "sda_bn_finalize": (i32, [vp, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "sda_reduce_stats": (i32, [vp, i32, vp, vp, i32, vp]),
     "sda_bn_gelu_backward_from_stats": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, f64, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_bn_gelu_backward_from_stats_dg": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, f64, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_bn_gelu_forward": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_bn_gelu_backward_reduce": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sda_bn_gelu_backward_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, f64, vp, vp, i32, i32, i32, i32, vp]),
+    "sda_bn_gelu_backward_apply_dg": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, f64, vp, vp, i32, i32, i32, i32, vp]),
     "sda_reduce_scratch_floats": (i32, [i32]),
     "sda_glu_forward": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sda_glu_backward": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -143,6 +143,13 @@ def rows_sumsq(x: torch.Tensor, B: int, row_elems: int, pitch: int) -> torch.Ten
     return out
 
 
+def rows_sumsq_from_row_parts(parts: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    """Per-sample sum of squares from the per-row partial sums conv_gemm(row_sumsq=parts) wrote."""
+    out = torch.empty(B, dtype=torch.float32, device=parts.device)
+    L.check(L.load().sda_rows_sumsq_from_row_parts(_p(parts), parts.shape[1], _p(out), B, T, _st()), "rows_sumsq_from_row_parts")
+    return out
+
+
 def rows_sumsq_from_stats(stats: torch.Tensor, B: int) -> torch.Tensor:
     """Per-sample sum of squares of a conv output from the per-tile statistics its epilogue wrote (plane 1)."""
     out = torch.empty(B, dtype=torch.float32, device=stats.device)
@@ -343,11 +350,24 @@ def conv_tile_co(Cout_p: int, KS: int = 3, stats: bool = False) -> int:
 
 
 def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=None, stats=None, gelu=False,
-              alg_dims=None, flags=0, bn_x=None, bn_coef=None, glu_bwd=None):
+              alg_dims=None, flags=0, bn_x=None, bn_coef=None, glu_bwd=None, gelu_bwd_u=None, row_sumsq=None):
     """RL conv: x (rows, Cin_p), w (nW, KS, Cout_p, Cin_p) packed, y (rows, Cout_p).
-    alg_dims = (Cin, Cout) unpadded, only used to count algorithmic FLOPs when the timer is on."""
+    alg_dims = (Cin, Cout) unpadded, only used to count algorithmic FLOPs when the timer is on.
+    gelu_bwd_u (flat 1x1 only, SDA_EPI_GELU_BWD): y = round(conv) * GELU'(gelu_bwd_u), `stats` = per-unit column sums.
+    row_sumsq (flat 1x1 only, SDA_EPI_ROW_SUMSQ): float (rows, Cout_p / 128) buffer of per-row partial sums of squares."""
     _need_cuda(x, w, y)
     a = L.ConvArgs()
+    if gelu_bwd_u is not None:
+        if bn_x is not None or gelu_bwd_u.shape != y.shape or stats is None:
+            raise L.SdaError("conv_gemm: gelu_bwd_u needs the shape of y and a stats buffer")
+        flags |= L.EPI_GELU_BWD
+        bn_x = gelu_bwd_u
+    if row_sumsq is not None:
+        if stats is not None or row_sumsq.dtype != torch.float32 or row_sumsq.shape[0] < B * L.rows_tp(T) \
+                or y.shape[1] % 128 or row_sumsq.shape[1] != y.shape[1] // 128:
+            raise L.SdaError("conv_gemm: row_sumsq must be float (rows, Cout_p / 128) and excludes stats")
+        flags |= L.EPI_ROW_SUMSQ
+        stats = row_sumsq
     a.x, a.w, a.bias, a.res, a.y, a.y_pre = _p(x), _p(w), _p(bias), _p(res), _p(y), _p(y_pre)
     a.widx, a.stats, a.partial = _p(widx), _p(stats), None
     a.bn_x, a.bn_coef = _p(bn_x), _p(bn_coef)
@@ -362,7 +382,7 @@ def conv_gemm(x, w, y, *, B, T, KS, dil, bias=None, res=None, y_pre=None, widx=N
     a.B, a.T, a.Cin_p, a.Cout_p, a.KS, a.dil = B, T, x.shape[1], Cout_p, KS, dil
     if glu and (res is not None or stats is not None or bn_x is not None or (y_pre is not None and y_pre.shape != y.shape)):
         raise L.SdaError("conv_gemm: EPI_GLU takes no residual / statistics and a gate buffer of y's shape")
-    if bn_x is not None and (bn_x.shape != y.shape or bn_coef is None or bn_coef.numel() != 4 * y.shape[1] or stats is None):
+    if bn_x is not None and gelu_bwd_u is None and (bn_x.shape != y.shape or bn_coef is None or bn_coef.numel() != 4 * y.shape[1] or stats is None):
         raise L.SdaError("conv_gemm: bn_x needs the shape of y, a [4][Cout_p] coefficient table and a stats buffer")
     if w.shape[-1] != x.shape[1] or w.shape[-2] != Cout_p or w.shape[-3] != KS:
         raise L.SdaError(f"conv_gemm: weight {tuple(w.shape)} does not match x {tuple(x.shape)} / y {tuple(y.shape)}")
@@ -447,7 +467,7 @@ def reduce_scratch(Cp, device):
     return torch.empty(L.load().sda_reduce_scratch_floats(Cp), dtype=torch.float32, device=device)
 
 
-def bn_gelu_backward(dy, x, mean, rstd, gamma, beta, dx, B, T, scratch, count=None, allreduce=None, tile_stats=None):
+def bn_gelu_backward(dy, x, mean, rstd, gamma, beta, dx, B, T, scratch, count=None, allreduce=None, tile_stats=None, dy_is_dg=False):
     """Returns (dgamma, dbeta) summed over `count` rows (global sums when `allreduce` is given) and fills dx.
     tile_stats: per-tile (sum dg, sum dg*xhat) already produced by the conv that wrote dy (conv_gemm(bn_x=...));
     without it the sums take a pass of their own over dy and x."""
@@ -457,7 +477,8 @@ def bn_gelu_backward(dy, x, mean, rstd, gamma, beta, dx, B, T, scratch, count=No
     lib = L.load()
     if tile_stats is not None and allreduce is None:          # single process: sums + coefficients in one launch
         coef = torch.empty(6 * Cp, dtype=torch.float32, device=x.device)
-        L.check(lib.sda_bn_gelu_backward_from_stats(_p(tile_stats), tile_stats.shape[0], _p(dy), _p(x), _p(mean), _p(rstd),
+        fn = lib.sda_bn_gelu_backward_from_stats_dg if dy_is_dg else lib.sda_bn_gelu_backward_from_stats
+        L.check(fn(_p(tile_stats), tile_stats.shape[0], _p(dy), _p(x), _p(mean), _p(rstd),
                                                     _p(gamma), _p(beta), gamma.numel(), float(count if count is not None else B * T),
                                                     _p(dgamma), _p(dbeta), _p(coef), _p(dx), B, T, Cp, dt_code(x.dtype), _st()),
                 "bn_gelu_backward_from_stats")
@@ -470,7 +491,10 @@ def bn_gelu_backward(dy, x, mean, rstd, gamma, beta, dx, B, T, scratch, count=No
     if allreduce is not None:
         allreduce(sums)
     coef = torch.empty(6 * Cp, dtype=torch.float32, device=x.device)
-    L.check(lib.sda_bn_gelu_backward_apply(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), gamma.numel(), _p(dgamma),
+    if dy_is_dg and tile_stats is None:
+        raise L.SdaError("bn_gelu_backward: dy_is_dg needs the statistics rows of the conv that wrote dg")
+    fn = lib.sda_bn_gelu_backward_apply_dg if dy_is_dg else lib.sda_bn_gelu_backward_apply
+    L.check(fn(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), gamma.numel(), _p(dgamma),
                                            _p(dbeta), float(count if count is not None else B * T), _p(coef), _p(dx), B, T, Cp,
                                            dt_code(x.dtype), _st()), "bn_gelu_backward_apply")
     return dgamma, dbeta

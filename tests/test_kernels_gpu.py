@@ -231,6 +231,84 @@ def test_conv1_per_sample_weights_and_gelu(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,T,B", [(320, 640, 360, 5), (640, 1024, 129, 3), (64, 160, 40, 7), (100, 128, 77, 2),
+                                          (1024, 640, 200, 3), (192, 384, 1, 9)])
+def test_conv1_flat_tiles_equal_tile_kernel(ops, dtype, cin, cout, T, B):
+    """conv1_flat (SDA_CONV_FLAT_TILES, kernel size 1) against conv_gemm's tile-per-workgroup kernel: same contraction order,
+    so bit-equal; plain, and with bias + saved pre-activation + GELU (conv_final1/2, models.py:194-195)."""
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(11)
+    Cip, Cop = L.pad_channels(cin), L.pad_channels(cout)
+    x = q(torch.randn(B, cin, T, generator=g), dtype)
+    w = q(torch.randn(cout, cin, 1, generator=g) / math.sqrt(cin), dtype)
+    bias = ops.pack_vector(torch.randn(cout, generator=g).to(DEV), Cop)
+    xb = to_rows(ops, x, dtype)
+    wp = ops.pack_conv_weight(w.to(DEV), Cop, Cip, dtype)
+    if Cop % 160 and Cop % 128:
+        pytest.skip("no flat tiling for this width")
+    for kw in (dict(), dict(bias=bias, gelu=True, with_pre=True)):
+        outs = []
+        for flags in (0, L.CONV_FLAT_TILES):
+            kw2 = dict(kw)
+            y, pre = ops.new_rows(B, T, Cop, dtype, DEV), ops.new_rows(B, T, Cop, dtype, DEV)
+            if kw2.pop("with_pre", False):
+                kw2["y_pre"] = pre
+            ops.conv_gemm(xb, wp, y, B=B, T=T, KS=1, dil=0, flags=flags, **kw2)
+            outs.append((y, pre))
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert torch.equal(outs[0][1], outs[1][1])
+    ref = TF.conv1d(x, w)
+    np.testing.assert_allclose(from_rows(ops, ops.conv_gemm(xb, wp, ops.new_rows(B, T, Cop, dtype, DEV), B=B, T=T, KS=1, dil=0,
+                                                            flags=L.CONV_FLAT_TILES), B, cout, T).numpy(), ref.numpy(), **tol(dtype, cin))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,T,B", [(1024, 640, 360, 4), (128, 256, 77, 3), (64, 320, 130, 6)])
+def test_conv1_flat_gelu_backward_epilogue(ops, dtype, cin, cout, T, B):
+    """SDA_EPI_GELU_BWD: the data-gradient conv's epilogue multiplies by GELU'(u) and sums the columns = conv, store, then
+    sda_gelu_backward_colsum (bit-equal gradient; the column sums agree to summation order)."""
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(12)
+    Cip, Cop = L.pad_channels(cin), L.pad_channels(cout)
+    xb = to_rows(ops, q(torch.randn(B, cin, T, generator=g), dtype), dtype)
+    wp = ops.pack_conv_weight(q(torch.randn(cout, cin, 1, generator=g) / math.sqrt(cin), dtype).to(DEV), Cop, Cip, dtype)
+    ub = to_rows(ops, q(torch.randn(B, cout, T, generator=g), dtype), dtype)
+    dg = ops.conv_gemm(xb, wp, ops.new_rows(B, T, Cop, dtype, DEV), B=B, T=T, KS=1, dil=0)
+    du_ref = ops.new_rows(B, T, Cop, dtype, DEV)
+    cs_ref = ops.gelu_backward_colsum(ub, dg, du_ref, B, T, ops.reduce_scratch(Cop, DEV))
+    du = ops.new_rows(B, T, Cop, dtype, DEV)
+    st = torch.full((ops.conv_stats_rows(B, T, 1, Cop, L.CONV_FLAT_TILES | L.EPI_GELU_BWD), 2, Cop), float("nan"), device=DEV)
+    ops.conv_gemm(xb, wp, du, B=B, T=T, KS=1, dil=0, flags=L.CONV_FLAT_TILES, gelu_bwd_u=ub, stats=st)
+    assert torch.equal(du, du_ref)
+    assert bool(torch.isfinite(st).all()) and float(st[:, 1].abs().max()) == 0.0
+    t = tol(dtype, B * T)
+    np.testing.assert_allclose(st[:, 0].double().sum(0).cpu().numpy(), cs_ref.double().cpu().numpy(), rtol=1e-4, atol=t["atol"] * 1e-2 + 1e-4)
+    with pytest.raises(L.SdaError):          # the epilogue exists in the flat form only
+        ops.conv_gemm(xb, wp, du, B=B, T=T, KS=1, dil=0, gelu_bwd_u=ub, stats=st)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,T,B", [(640, 1024, 360, 3), (64, 128, 50, 5), (128, 512, 129, 2)])
+def test_conv1_flat_row_sumsq_epilogue(ops, dtype, cin, cout, T, B):
+    """SDA_EPI_ROW_SUMSQ + sda_rows_sumsq_from_row_parts: per-sample ||y_b||^2 of the stored output without a pass over it
+    (the brain-embedding norms of CLIPLoss, loss.py:65)."""
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(13)
+    Cip, Cop = L.pad_channels(cin), L.pad_channels(cout)
+    xb = to_rows(ops, q(torch.randn(B, cin, T, generator=g), dtype), dtype)
+    wp = ops.pack_conv_weight(q(torch.randn(cout, cin, 1, generator=g) / math.sqrt(cin), dtype).to(DEV), Cop, Cip, dtype)
+    bias = ops.pack_vector(torch.randn(cout, generator=g).to(DEV), Cop)
+    y0 = ops.conv_gemm(xb, wp, ops.new_rows(B, T, Cop, dtype, DEV), B=B, T=T, KS=1, dil=0, bias=bias, gelu=True)
+    parts = torch.full((L.rows_alloc(B, T), Cop // 128), float("nan"), device=DEV)
+    y = ops.conv_gemm(xb, wp, ops.new_rows(B, T, Cop, dtype, DEV), B=B, T=T, KS=1, dil=0, bias=bias, gelu=True,
+                      flags=L.CONV_FLAT_TILES, row_sumsq=parts)
+    assert torch.equal(y, y0)
+    norms = ops.rows_sumsq_from_row_parts(parts, B, T)
+    ref = from_rows(ops, y, B, cout, T).double().pow(2).sum(dim=(1, 2))
+    np.testing.assert_allclose(norms.cpu().double().numpy(), ref.numpy(), rtol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,dil,T,glu", [(40, 48, 2, 70, False), (320, 320, 4, 200, False),
                                                 (64, 48, 2, 90, True), (320, 640, 2, 140, True)])
 def test_conv3_dgrad_and_wgrad(ops, dtype, cin, cout, dil, T, glu):
@@ -310,6 +388,27 @@ def test_conv3_bn_backward_statistics_epilogue(ops, dtype, cin, cout, dil, T, ti
     assert float((db - db_ref).abs().max()) <= 1e-5 * (float(db_ref.abs().max()) + 1e-6) * (1 if dtype == torch.float32 else 4)
     np.testing.assert_allclose(from_rows(ops, dx2, B, cout, T).numpy(), from_rows(ops, dx1, B, cout, T).numpy(),
                                rtol=1e-3, atol=1e-4 if dtype == torch.float32 else 2e-2)
+    # SDA_EPI_BN_STORE_DG: the conv stores dg = dy * GELU'(u) (rounded) instead of dy, statistics of dg as stored; the
+    # BatchNorm backward is finished without a second GELU' (fp32: the same arithmetic; 16-bit: one more rounding of dg)
+    out_dg = ops.new_rows(B, T, Cout_p, dtype, DEV)
+    st_dg = torch.full_like(st, float("nan"))
+    ops.conv_gemm(dyb, wp, out_dg, B=B, T=T, KS=3, dil=dil, res=res, stats=st_dg, bn_x=h, bn_coef=coef, flags=tiling | L.EPI_BN_STORE_DG)
+    u = ops.unpack_rows(h, B, cout, T)
+    u = (u - mean[:cout, None]) * rstd[:cout, None] * gamma[:, None] + beta[:, None]
+    uu = u.double()
+    gprime = 0.5 * (1 + torch.erf(uu / math.sqrt(2))) + uu * torch.exp(-0.5 * uu * uu) / math.sqrt(2 * math.pi)
+    dg_expect = (ops.unpack_rows(out, B, cout, T).double() * gprime).float().cpu()
+    np.testing.assert_allclose(from_rows(ops, out_dg, B, cout, T).numpy(), dg_expect.numpy(), **tol(dtype))
+    dx3 = ops.new_rows(B, T, Cout_p, dtype, DEV)
+    dg3, db3 = ops.bn_gelu_backward(out_dg, h, mean, rstd, gamma, beta, dx3, B, T, ops.reduce_scratch(Cout_p, DEV), tile_stats=st_dg,
+                                    dy_is_dg=True)
+    loose = 1e-5 if dtype == torch.float32 else (2e-3 if dtype == torch.float16 else 1e-2)
+    assert float((dg3 - dg_ref).abs().max()) <= loose * scale * 4
+    assert float((db3 - db_ref).abs().max()) <= loose * (float(db_ref.abs().max()) + 1e-6) * 4
+    # (16-bit: the extra rounding moves some outputs by one unit in the last place, 2^-7 / 2^-10 relative)
+    np.testing.assert_allclose(from_rows(ops, dx3, B, cout, T).numpy(), from_rows(ops, dx1, B, cout, T).numpy(),
+                               rtol={torch.float32: 1e-3, torch.float16: 2e-3, torch.bfloat16: 1e-2}[dtype],
+                               atol=1e-4 if dtype == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
