@@ -57,8 +57,7 @@ enum { SDA_EPI_GELU = 1,
                                        Cout_p % 160 == 0 or Cout_p % 128 == 0, shared weights, no residual / statistics:
                                        the same tiling (conv1_flat.hip); other shapes ignore the flag.  `stats` then has
                                        sda_conv_stats_rows(...) rows instead of B * n_t_tiles */
-       /* two epilogues of the flat kernel-size-1 form only (SDA_CONV_FLAT_TILES must be set, else the call fails): */
-       SDA_EPI_GELU_BWD = 65536,    /* the conv's output is the gradient entering a GELU whose input u = bn_x ([rows][Cout_p],
+       SDA_EPI_GELU_BWD = 65536,    /* kernel size 1 (flat tiles or one tile per workgroup): the conv's output is the gradient entering a GELU whose input u = bn_x ([rows][Cout_p],
                                        same layout as y) the forward kept: y = round(conv) * GELU'(u) (what sda_gelu_backward_colsum
                                        computes from the stored gradient), `stats` rows (sda_conv_stats_rows) = per-unit column
                                        sums of the products in plane 0 (the bias gradient of the layer that fed the GELU), plane 1
@@ -67,7 +66,7 @@ enum { SDA_EPI_GELU = 1,
                                        rounded to the storage type, INSTEAD of dy, and the statistics are those of dg as stored —
                                        sda_bn_gelu_backward_from_stats_dg / _apply_dg then finish the BatchNorm backward without
                                        evaluating GELU' a second time */
-       SDA_EPI_ROW_SUMSQ = 131072   /* Cout_p % 128 == 0: `stats` = float [>= B * (T + SDA_ROW_PAD) rows][Cout_p / 128]; entry
+       SDA_EPI_ROW_SUMSQ = 131072   /* the flat kernel-size-1 form only (SDA_CONV_FLAT_TILES must be set, else the call fails), Cout_p % 128 == 0: `stats` = float [>= B * (T + SDA_ROW_PAD) rows][Cout_p / 128]; entry
                                        [r][j] = sum of squares of buffer row r's output channels [128 j, 128 j + 128) as stored
                                        (rows that are padding are not written); sda_rows_sumsq_from_row_parts turns them into
                                        per-sample norms */ };

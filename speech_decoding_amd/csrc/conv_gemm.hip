@@ -68,6 +68,7 @@ template <> __device__ inline float4 round_like<uint16_t>(float4 v) {
 // per K-step and wave, a third of the MFMA time beside it.
 // BN: 0 = off, 1 = BatchNorm-backward statistics epilogue (bn_x), 2 = the same storing dg instead of dy (SDA_EPI_BN_STORE_DG;
 // a template parameter, not a branch: with both forms in one kernel the code grew by 15 % and the step by 0.13 ms)
+// (3 = SDA_EPI_GELU_BWD, kernel size 1: bn_x is the GELU's input)
 template <typename E, int TILE_CO, int KS, int NT, int BN = 0, bool SV = true>
 __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_args a, const int n_t_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
   const long out_row0 = a.x_row0 + (long)b * a.x_sample_rows + t0;
   // BatchNorm-backward statistics mode (BN): this thread's CH channels of (gamma, beta, mean, rstd)
   float bga[BN ? CH : 1], bbe[BN ? CH : 1], bmu[BN ? CH : 1], brs[BN ? CH : 1];
-  if constexpr (BN) {
+  if constexpr (BN == 1 || BN == 2) {
     if (active) {
 #pragma unroll
       for (int q4 = 0; q4 < CH / 4; ++q4) {
@@ -526,7 +527,20 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
               continue;
             }
           }
-          if constexpr (BN) {
+          if constexpr (BN == 3) {
+            // SDA_EPI_GELU_BWD (kernel size 1): v = the gradient entering a GELU whose input u = bn_x the forward kept — write
+            // round(v) * GELU'(u), bwd_colsum_kernel<E, 0>'s expression on the gradient as it would have been stored, and keep
+            // the column sums of the products (the bias gradient of the layer that fed the GELU)
+            float u8[CH];
+            Vec16<E>::unpack(bx[it], u8);
+#pragma unroll
+            for (int j = 0; j < CH; j += 2) {
+              const f32x2 o = f32x2{Vec16<E>::round(v[j]), Vec16<E>::round(v[j + 1])} * gelu_grad_pair<E>(f32x2{u8[j], u8[j + 1]});
+              v[j] = o.x; v[j + 1] = o.y;
+              ssum[j] += o.x; ssum[j + 1] += o.y;
+            }
+            Vec16<E>::store(yg + off, v);
+          } else if constexpr (BN) {
             // BatchNorm+GELU backward sums of the layer this gradient enters (what col_reduce_kernel<E, 1>
             // computes in a pass of its own): dg = dy * GELU'(gamma * xhat + beta) with dy as stored.
             // SDA_EPI_BN_STORE_DG: dg itself is what gets stored (and summed as stored) — the pass that finishes the
@@ -606,18 +620,21 @@ static int dispatch_conv_nt(const sda_conv_args& a, hipStream_t st) {
   // the CU — the forward pass — and keeps the single-tile form (two 80 KB workgroups per CU, room for one
   // weight-gradient workgroup beside them) in backward, where the paired form measured slower end to end.
   const bool pair = !a.widx && a.ksplit == 1 && (a.flags & SDA_CONV_PAIR_TILES) && !(a.flags & SDA_CONV_SINGLE_TILE);
-  if (a.bn_x) {                 // BatchNorm-backward statistics epilogue: data-gradient convs of the k = 3 layers
+  const bool gelu_bwd = a.flags & SDA_EPI_GELU_BWD;
+  if (a.bn_x && !gelu_bwd) {    // BatchNorm-backward statistics epilogue: data-gradient convs of the k = 3 layers
     if (!k3) { set_error("conv_gemm: bn_x is built for kernel size 3 only"); return -1; }
   }
+  if (gelu_bwd && (k3 || pair || a.widx)) { set_error("conv_gemm: SDA_EPI_GELU_BWD is built for kernel size 1, shared weights, one tile per workgroup"); return -1; }
   // scalar-base DMA needs whole 16-row pieces inside the operands: row-layout activations (slack rows behind the last
   // sample) and fully padded weights; the split-K matrix mode (plain matrices, ragged row counts) keeps per-lane addresses
   const bool sv = a.x_row0 >= PAD && a.x_sample_rows >= a.T + PAD && a.w_rows_limit >= a.Cout_p && !a.partial &&
                   a.x_rows_limit >= a.x_row0 + (long)(a.B - 1) * a.x_sample_rows + (long)n_t * TILE_T + 2 * PAD &&
                   (long)a.x_pitch * 16 * (long)sizeof(E) < (1L << 31) && (long)a.w_pitch * 16 * (long)sizeof(E) < (1L << 31);
   if (!sv) {
-    if (k3 || pair) { set_error("conv_gemm: kernel-3 / paired-tile launches need row-layout operands"); return -1; }
+    if (k3 || pair || gelu_bwd) { set_error("conv_gemm: kernel-3 / paired-tile / GELU-backward launches need row-layout operands"); return -1; }
     return launch_conv<E, TILE_CO, 1, 1, 0, false>(a, st);
   }
+  if (gelu_bwd) return launch_conv<E, TILE_CO, 1, 1, 3>(a, st);
   if (a.bn_x && (a.flags & SDA_EPI_BN_STORE_DG)) return pair ? launch_conv<E, TILE_CO, 3, 2, 2>(a, st) : launch_conv<E, TILE_CO, 3, 1, 2>(a, st);
   if (a.bn_x) return pair ? launch_conv<E, TILE_CO, 3, 2, 1>(a, st) : launch_conv<E, TILE_CO, 3, 1, 1>(a, st);
   if (pair) return k3 ? launch_conv<E, TILE_CO, 3, 2>(a, st) : launch_conv<E, TILE_CO, 1, 2>(a, st);
@@ -632,8 +649,13 @@ static int dispatch_conv(const sda_conv_args& a, hipStream_t st) {
     return launch_conv3_flat(a, st);
   }
   if ((a.flags & SDA_CONV_FLAT_TILES) && a.KS == 1 && conv1_flat_supports(a)) return launch_conv1_flat(a, st);
-  if (a.flags & (SDA_EPI_GELU_BWD | SDA_EPI_ROW_SUMSQ)) {
-    set_error("conv_gemm: SDA_EPI_GELU_BWD / SDA_EPI_ROW_SUMSQ need SDA_CONV_FLAT_TILES and a plain row-layout kernel-1 convolution");
+  if (a.flags & SDA_EPI_ROW_SUMSQ) {
+    set_error("conv_gemm: SDA_EPI_ROW_SUMSQ needs SDA_CONV_FLAT_TILES and a plain row-layout kernel-1 convolution with Cout_p % 128 == 0");
+    return -1;
+  }
+  if ((a.flags & SDA_EPI_GELU_BWD) && (!a.bn_x || !a.stats || a.bias || a.y_pre || a.res || a.partial || a.KS != 1 ||
+                                       (a.flags & (SDA_EPI_GELU | SDA_EPI_GLU | SDA_EPI_GLU_BWD)))) {
+    set_error("conv_gemm: SDA_EPI_GELU_BWD needs kernel size 1, bn_x (the GELU's input) and stats, and no bias / y_pre / residual / other epilogue");
     return -1;
   }
   if (a.flags & SDA_EPI_GLU) { set_error("conv_gemm: SDA_EPI_GLU needs SDA_CONV_FLAT_TILES, kernel size 3 and Cout_p % 160 == 0"); return -1; }

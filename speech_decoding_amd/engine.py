@@ -102,7 +102,10 @@ class EncoderEngine:
                                              # times: 68.6 -> 67.3 us per 320 -> 320 conv with the priority hand-over, round 4),
                                              # 64 = no priority hand-over between the two (diagnostic)
         self.fuse_glu_forward = True         # F.glu in conv2's epilogue (flat-tile kernel, D2p % 80 == 0): no [value | gate] buffer
-        self.bias_sums_on_side = True        # final reduction of the bias-gradient column sums on the weight-gradient stream
+        self.bias_sums_on_side = False       # final reduction of the bias-gradient column sums on the weight-gradient stream
+                                             # (round 3: on; re-measured in round 4 against the same library, three alternations on
+                                             # one box: 7.15-7.20 ms on, 7.09-7.14 ms off — the short reductions delay the
+                                             # weight-gradient GEMMs queued behind them more than they cost the main stream)
         self.fuse_glu_backward = False       # the GLU backward in the epilogue of the conv that produces its incoming gradient
                                              # (needs the fused forward: bufs hold (out, gate)); not with flat-tile data gradients.
                                              # Off: measured 7.87 vs 7.77 ms — the separate pass is HBM-bound and runs beside the
@@ -124,6 +127,11 @@ class EncoderEngine:
                                              # their statistics epilogue computes anyway) instead of dy: the pass that applies the
                                              # BatchNorm backward does not evaluate GELU' again (SDA_EPI_BN_STORE_DG; a SIMD issues
                                              # MFMA and ordinary vector instructions through one port)
+        self.fuse_gelu_backward_1x1 = False  # conv_final2's data gradient applies conv_final1's GELU backward in its epilogue and keeps
+                                             # the bias-gradient column sums (SDA_EPI_GELU_BWD): no pass over the 640-wide gradient.
+                                             # Off: measured 7.10 vs 7.04 ms — like the GLU backward below, the separate pass is
+                                             # HBM-bound and runs beside the weight-gradient stream for free; vector work added to an
+                                             # MFMA kernel's epilogue takes the matrix pipe's issue slots
         self.flat_1x1_forward = False
         self.flat_1x1_backward = False
         self.flat_1x1_options = 0            # extra conv1_flat flags (1024 = staggered tile order, 32768 = one workgroup per CU)
@@ -639,7 +647,7 @@ class EncoderEngine:
         grads["f2b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u2"], dZt, du2, width=d.Fp, then=lambda cs: bias_grad(cs, d.F))
         b1_flags = (L.CONV_FLAT_TILES | self.flat_1x1_options) if self.flat_1x1_backward else 0
         du1 = tmp("du1", d.F1p)
-        if b1_flags and (d.F1p % 160 == 0 or d.F1p % 128 == 0):
+        if self.fuse_gelu_backward_1x1 or (b1_flags and (d.F1p % 160 == 0 or d.F1p % 128 == 0)):
             # conv_final2's data gradient with conv_final1's GELU backward in its epilogue: du1 directly, plus per-unit column sums
             gst = torch.empty((ops.conv_stats_rows(B, T, 1, d.F1p, b1_flags | L.EPI_GELU_BWD), 2, d.F1p), dtype=torch.float32, device=dev)
             ops.conv_gemm(du2, ctx.packed_T["f2w"], du1, B=B, T=T, KS=1, dil=0, gelu_bwd_u=bufs["u1"], stats=gst,

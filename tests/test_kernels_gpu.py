@@ -283,8 +283,13 @@ def test_conv1_flat_gelu_backward_epilogue(ops, dtype, cin, cout, T, B):
     assert bool(torch.isfinite(st).all()) and float(st[:, 1].abs().max()) == 0.0
     t = tol(dtype, B * T)
     np.testing.assert_allclose(st[:, 0].double().sum(0).cpu().numpy(), cs_ref.double().cpu().numpy(), rtol=1e-4, atol=t["atol"] * 1e-2 + 1e-4)
-    with pytest.raises(L.SdaError):          # the epilogue exists in the flat form only
-        ops.conv_gemm(xb, wp, du, B=B, T=T, KS=1, dil=0, gelu_bwd_u=ub, stats=st)
+    # the same epilogue in the tile-per-workgroup kernel (statistics rows per (sample, 128-row tile))
+    du2 = ops.new_rows(B, T, Cop, dtype, DEV)
+    st2 = torch.full((ops.conv_stats_rows(B, T, 1, Cop, 0), 2, Cop), float("nan"), device=DEV)
+    ops.conv_gemm(xb, wp, du2, B=B, T=T, KS=1, dil=0, gelu_bwd_u=ub, stats=st2)
+    assert torch.equal(du2, du_ref)
+    assert bool(torch.isfinite(st2).all()) and float(st2[:, 1].abs().max()) == 0.0
+    np.testing.assert_allclose(st2[:, 0].double().sum(0).cpu().numpy(), cs_ref.double().cpu().numpy(), rtol=1e-4, atol=t["atol"] * 1e-2 + 1e-4)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
