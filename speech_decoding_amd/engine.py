@@ -123,10 +123,12 @@ class EncoderEngine:
         # partial sums of squares instead of per-tile statistics for ||Z_b||^2), and their data gradients — conv_final2's with
         # the GELU backward of conv_final1 and its bias-gradient column sums in the epilogue (SDA_EPI_GELU_BWD: no
         # gelu_backward_colsum pass over the 640-wide gradient)
-        self.bn_backward_store_dg = True     # the data-gradient convs that feed a BatchNorm+GELU backward store dg = dy * GELU'(u) (which
+        self.bn_backward_store_dg = False    # the data-gradient convs that feed a BatchNorm+GELU backward store dg = dy * GELU'(u) (which
                                              # their statistics epilogue computes anyway) instead of dy: the pass that applies the
-                                             # BatchNorm backward does not evaluate GELU' again (SDA_EPI_BN_STORE_DG; a SIMD issues
-                                             # MFMA and ordinary vector instructions through one port)
+                                             # BatchNorm backward does not evaluate GELU' again (SDA_EPI_BN_STORE_DG).  Off: worth
+                                             # 0.02 ms of 7.16 (that pass is HBM-bound either way), and the extra rounding of dg to
+                                             # bf16 moves the conv2 bias gradients — almost cancelling sums over 92 160 rows — from
+                                             # under to over their 6e-2 parity bound at the full batch (7.7e-2)
         self.fuse_gelu_backward_1x1 = False  # conv_final2's data gradient applies conv_final1's GELU backward in its epilogue and keeps
                                              # the bias-gradient column sums (SDA_EPI_GELU_BWD): no pass over the 640-wide gradient.
                                              # Off: measured 7.10 vs 7.04 ms — like the GLU backward below, the separate pass is
