@@ -20,6 +20,13 @@
 
 namespace sda {
 
+// One LDS-DMA piece, lean form (conv3_flat.hip's): wave-uniform 64-bit base the caller computed with scalar arithmetic well
+// ahead (no VALU-written SGPR feeds the load: no s_nop 4), one per-lane byte offset register, M0 written in the statement
+// that reads it.  tools/check_dma_hazard.py walks the listing for hazards.
+__device__ __forceinline__ void wg_dma16_lean(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 namespace {
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
 template <int B, int E, typename F> __device__ __forceinline__ void wg_static_for(F&& f) {
@@ -216,8 +223,33 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
   const E* dy_base = dyg;            // wave-uniform bases of the chunk being staged (fast path)
   const E* x_base = xg;
   uint32_t nxt_off = 0;
+  const uint32_t lds_w = lds_base + (uint32_t)wid * 1024u;   // this wave's share of a piece index: a destination is lds_w + stage + a constant
   // chunk `it` -> is it a fast one?  sets the bases; the slow path stages it at once
+  // Flat rows: chunk `it` starts KT rows behind chunk it - 1, so its two bases are running pointers advanced by a constant
+  // stride per chunk, and "is it a fast one" is one compare — the leading n_fast chunks are (full chunk, input rows inside the
+  // buffer): the general form below recomputes rows, bounds and two 64-bit products per chunk, ~70 scalar instructions at the
+  // top of every chunk, in front of its first fragment reads.
+  int n_fast = 0;
+  const E* dy_run = dyg;
+  const E* x_run = xg;
+  const size_t dy_stride = (size_t)KT * a.dy_pitch, x_stride = (size_t)KT * a.x_pitch;
+  if (flat && seg_r0 >= halo) {
+    const long n_full = (seg_r1 - seg_r0) / KT, n_ub = (a.rows_limit - halo - seg_r0) / KT;
+    n_fast = (int)(n_full < n_ub ? n_full : n_ub);
+    if (n_fast < 0) n_fast = 0;
+    dy_run = dyg + (size_t)(seg_r0 + KT) * a.dy_pitch + co0;              // chunk 1 (chunk 0 is staged in front of the loop)
+    x_run = xg + (size_t)(seg_r0 + KT - halo) * a.x_pitch + ci0;
+  }
   auto prepare = [&](int it, int buf) -> bool {
+    if (flat) {
+      const bool f = it < n_fast;
+      if (f) { dy_base = dy_run; x_base = x_run; nxt_off = (uint32_t)(buf * G::STAGE); }
+      dy_run += dy_stride;
+      x_run += x_stride;
+      if (f) return true;
+      stage(it, buf);
+      return false;
+    }
     describe(it);
     const long xrow0 = c_row - halo;
     if (c_valid == KT && xrow0 >= 0 && xrow0 + KT + 2 * halo <= a.rows_limit) {
@@ -237,10 +269,10 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
     constexpr int j = decltype(jc)::value;
     if constexpr (j < NDY) {
       const int pc = wid + 4 * j;
-      if (pc < G::DY_PIECES) lds_dma16_sv(dy_base, vdy[j], lds_base + nxt_off + pc * 1024);
+      if (pc < G::DY_PIECES) wg_dma16_lean(dy_base, vdy[j], lds_w + nxt_off + (uint32_t)(j * 4096));
     } else if constexpr (j < NDY + NX) {
       const int pc = wid + 4 * (j - NDY);
-      if (pc < x_pieces) lds_dma16_sv(x_base, vx[j - NDY], lds_base + nxt_off + G::DY_BYTES + pc * 1024);
+      if (pc < x_pieces) wg_dma16_lean(x_base, vx[j - NDY], lds_w + nxt_off + (uint32_t)(G::DY_BYTES + (j - NDY) * 4096));
     }
   };
   constexpr int NPW = NDY + NX;                // pieces per wave and chunk (upper bound)
@@ -270,8 +302,8 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
   for (int it = 0; it < total; ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of chunk `it` landed
     __builtin_amdgcn_s_barrier();                       // everyone's landed; chunk it-1 fully consumed
-    const bool fast = (it + 1 < total) && prepare(it + 1, cur ^ 1);
     const unsigned char* dys = smem + cur * G::STAGE;
+    const int nxt = cur ^ 1;
     cur ^= 1;
     const unsigned char* xs = dys + G::DY_BYTES;
     // MFMA groups g = (kk, tap) of the chunk, software-pipelined IN THE SOURCE: group g + 1's x fragments (and, on a K-step's
@@ -301,6 +333,8 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
     uint4 af[MREP], bf[NREP];
     read_a(std::integral_constant<int, 0>{}, af);
     read_b(std::integral_constant<int, 0>{}, bf);
+    // (the next chunk is prepared AFTER this chunk's first fragment reads are on their way: its scalar work hides behind them)
+    const bool fast = (it + 1 < total) && prepare(it + 1, nxt);
     wg_static_for<0, NG>([&](auto gc) {
       constexpr int g = decltype(gc)::value, kk = g / KS, tap = g % KS;
       uint4 af_n[MREP], bf_n[NREP];
