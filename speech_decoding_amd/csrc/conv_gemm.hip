@@ -13,7 +13,7 @@
 // Epilogue: bias in registers -> LDS staging -> coalesced pass adding the residual, optional GELU,
 // BatchNorm partial statistics (per tile, deterministic), 8/16-byte stores.
 #include "sd_common.h"
-#include "conv_tile.h"
+#include "flat_tile.h"
 
 namespace sda {
 
@@ -146,11 +146,16 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
   const uint32_t xvoff = (uint32_t)(((size_t)prow * a.x_pitch + (size_t)((pchunk ^ sw64(prow)) * PER16)) * sizeof(E));
   const uint32_t wvoff = (uint32_t)(((size_t)prow * a.w_pitch + (size_t)((pchunk ^ sw64(prow)) * PER16)) * sizeof(E));
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  // (wave-uniform by construction; where hipcc cannot prove it — the two-tile form's tile select — this makes it provable,
+  // elsewhere it folds away)
+  auto uniform_u32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
   auto dma_x = [&](int s, int p, uint32_t lds_off) {           // input piece p (16 rows) of K-step s
     if constexpr (SV) {
       long srow = row_base + p * 16;
       srow = srow < 0 ? 0 : (srow > a.x_rows_limit - 16 ? a.x_rows_limit - 16 : srow);   // (never taken in row layout: slack rows)
-      lds_dma16_sv(xg + (size_t)srow * a.x_pitch + (size_t)s * SLAB, xvoff, lds_base + lds_off);
+      // (lean form: the base is scalar arithmetic on kernel arguments and block indices, no VALU-written SGPR feeds the load —
+      // tools/check_dma_hazard.py walks the listing)
+      lds_dma16_lean<false>(xg + (size_t)srow * a.x_pitch + (size_t)s * SLAB, xvoff, uniform_u32(lds_base + lds_off));
     } else {
       const int r = p * 16 + prow;
       long row = row_base + r;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
   };
   auto dma_w = [&](int s, int tap, int q, uint32_t lds_off) {  // weight piece q (16 output channels) of one tap
     if constexpr (SV) {
-      lds_dma16_sv(wg + ((size_t)tap * a.Cout_p + co0 + q * 16) * a.w_pitch + (size_t)s * SLAB, wvoff, lds_base + lds_off);
+      lds_dma16_lean<false>(wg + ((size_t)tap * a.Cout_p + co0 + q * 16) * a.w_pitch + (size_t)s * SLAB, wvoff, uniform_u32(lds_base + lds_off));
     } else {
       int co = co0 + q * 16 + prow;
       co = co < a.w_rows_limit ? co : a.w_rows_limit - 1;
@@ -295,6 +300,31 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
 #pragma unroll
       for (int tap = 0; tap < KS; ++tap) stage_w(s_begin, 0, tap);
     }
+    // Single tile, scalar bases: this wave's pieces of a slab are fixed for the whole K loop, so each keeps ONE per-lane byte
+    // offset (its rows inside the tile / the weight block) against two running scalar bases that advance one slab per
+    // K-step — an issue is an add for the LDS destination, the M0 write and the load (9-10 scalar instructions and an
+    // s_nop 4 per piece before; dispatch_conv_nt checks that the offsets fit 31 bits)
+    constexpr int L_NXW = 3, L_NWW = (KS * TP + NW - 1) / NW;
+    constexpr bool LEAN = NT == 1 && SV;
+    uint32_t xoff[LEAN ? L_NXW : 1], woff[LEAN ? L_NWW : 1];
+    const E* xrun = xg;
+    const E* wrun = wg;
+    uint32_t lds_xw = 0, lds_ww = 0;
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int j = 0; j < L_NXW; ++j) xoff[j] = xvoff + (uint32_t)((size_t)(((wid & 3) + 4 * j) * 16) * a.x_pitch * sizeof(E));
+#pragma unroll
+      for (int i = 0; i < L_NWW; ++i) {
+        int q = wid + NW * i;
+        q = q < KS * TP ? q : KS * TP - 1;
+        const int t2 = q / TP;
+        woff[i] = wvoff + (uint32_t)(((size_t)t2 * a.Cout_p + (size_t)(q - t2 * TP) * 16) * a.w_pitch * sizeof(E));
+      }
+      xrun = xg + (size_t)row_base * a.x_pitch + (size_t)(s_begin + 1) * SLAB;       // slab s + 1 of the first K-step
+      wrun = wg + (size_t)co0 * a.w_pitch + (size_t)(s_begin + 1) * SLAB;
+      lds_xw = uniform_u32(lds_base + tsel * XS_BYTES + (wid & 3) * 1024);
+      lds_ww = uniform_u32(lds_base + NT * XS_BYTES + wid * 1024);
+    }
     for (int s = s_begin; s < s_end; ++s) {
       const int cur = (s - s_begin) & 1;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of slab s have landed
@@ -305,13 +335,14 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
       if constexpr (NT == 1 && SV) {
         // this wave's pieces of slab s + 1 in need order (input first), PER of them after each row of MFMAs
         constexpr int NXW = 3, NWW = (KS * TP + NW - 1) / NW, PER = (NXW + NWW + 4 * KS - 1) / (4 * KS);
+        const uint32_t nxt = (uint32_t)((cur ^ 1) * STAGE);
         auto issue_j = [&](int j) {
           if (j < NXW) {
             const int pc = (wid & 3) + 4 * j;
-            if (pc < x_pieces) dma_x(s + 1, pc, (cur ^ 1) * STAGE + tsel * XS_BYTES + pc * 1024);
+            if (pc < x_pieces) lds_dma16_lean<false>(xrun, xoff[j], lds_xw + nxt + (uint32_t)(j * 4096));
           } else if (j < NXW + NWW) {
             const int q = wid + NW * (j - NXW);
-            if (q < KS * TP) { const int t2 = q / TP; dma_w(s + 1, t2, q - t2 * TP, (cur ^ 1) * STAGE + NT * XS_BYTES + q * 1024); }
+            if (q < KS * TP) lds_dma16_lean<false>(wrun, woff[j - NXW], lds_ww + nxt + (uint32_t)((j - NXW) * NW * 1024));
           }
         };
         compute_slab_spread(xs, ws, [&](int tap, int m) {
@@ -320,6 +351,8 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
             for (int i = 0; i < PER; ++i) issue_j((tap * 4 + m) * PER + i);
           }
         });
+        xrun += SLAB;
+        wrun += SLAB;
       } else {
         if (more) stage_x(s + 1, cur ^ 1);                // DMA of the next slab overlaps the MFMAs below
 #pragma unroll
@@ -629,7 +662,8 @@ static int dispatch_conv_nt(const sda_conv_args& a, hipStream_t st) {
   // sample) and fully padded weights; the split-K matrix mode (plain matrices, ragged row counts) keeps per-lane addresses
   const bool sv = a.x_row0 >= PAD && a.x_sample_rows >= a.T + PAD && a.w_rows_limit >= a.Cout_p && !a.partial &&
                   a.x_rows_limit >= a.x_row0 + (long)(a.B - 1) * a.x_sample_rows + (long)n_t * TILE_T + 2 * PAD &&
-                  (long)a.x_pitch * 16 * (long)sizeof(E) < (1L << 31) && (long)a.w_pitch * 16 * (long)sizeof(E) < (1L << 31);
+                  (long)a.x_pitch * XROWS * (long)sizeof(E) < (1L << 31) &&
+                  (long)a.w_pitch * ((long)a.KS * a.Cout_p + 16) * (long)sizeof(E) < (1L << 31);   // per-piece offsets: 31 bits
   if (!sv) {
     if (k3 || pair || gelu_bwd) { set_error("conv_gemm: kernel-3 / paired-tile / GELU-backward launches need row-layout operands"); return -1; }
     return launch_conv<E, TILE_CO, 1, 1, 0, false>(a, st);
