@@ -90,6 +90,10 @@ class EncoderEngine:
         # activation, never on each other or on the data-gradient chain: run them on a second HIP stream
         self.wgrad_flat_rows = True          # shared-weight gradients contract a segment's rows as one run (pad rows of dy are zero)
         self.wgrad_side_stream = True
+        self.wgrad_reduce_stream = False     # the K-split slab sums behind every weight-gradient GEMM (HBM-bound, 17 launches, 0.36 ms
+                                             # of the weight-gradient stream's 3.5 ms in the step) on a THIRD stream, so that the
+                                             # next GEMM does not queue behind them: measured 7.06-7.10 vs 6.99-7.07 ms (and 0.4 ms
+                                             # more host time per step for the extra events) — off
         self.side_stream_priority = 0        # HIP stream priority of the weight-gradient / packing stream
         self.probe = None                    # diagnostics (tools/stream_waits.py): a list collects (label, event, event) around
                                              # every point where the main stream waits for another stream
@@ -555,6 +559,10 @@ class EncoderEngine:
                         f.record_stream(side)
                 pending.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=side_group("grads", self.group), async_op=True))
                 return b
+            if red is not None:                   # the weight gradients of this group come from the slab-sum stream
+                ev = torch.cuda.Event()
+                ev.record(red)
+                side.wait_event(ev)
             bucket = on_side(pack_and_reduce)
             off = 0
             for n, f in zip(names, flats):
@@ -586,11 +594,21 @@ class EncoderEngine:
                 t.record_stream(main)
             return out
 
+        red = None
+        if side is not None and self.wgrad_reduce_stream:
+            red = self._side.get(str(dev) + "/reduce")
+            if red is None:
+                red = self._side[str(dev) + "/reduce"] = torch.cuda.Stream(device=dev)
+
         def join_side():
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record(side)
                 self._wait("weight-gradient stream joined", main, ev)
+            if red is not None:
+                ev = torch.cuda.Event()
+                ev.record(red)
+                self._wait("slab-sum stream joined", main, ev)
 
         def wgrad(dy, x, KS, dil, Cout, Cin, **glu):
             Cout_p, Cin_p = dy.shape[1], x.shape[1]
@@ -600,7 +618,15 @@ class EncoderEngine:
             def chain():
                 slabs = ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=perm, seg_start=seg, nseg=nseg,
                                        alg_dims=(Cin, Cout), flat_rows=self.wgrad_flat_rows)
-                return ops.reduce_unpack_wgrad(slabs, Cout, Cin, KS, **glu)
+                if red is None:
+                    return ops.reduce_unpack_wgrad(slabs, Cout, Cin, KS, **glu)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                red.wait_event(ev)
+                with torch.cuda.stream(red):
+                    out = ops.reduce_unpack_wgrad(slabs, Cout, Cin, KS, **glu)
+                slabs.record_stream(red)
+                return out
             return on_side(chain)
 
         ntile = B * ops.n_t_tiles(T)
