@@ -462,11 +462,12 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
             float x8[CH];
             Vec16<E>::unpack(bx_cur, x8);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-              float dg = Vec16<E>::round(v[j]) * gelu_grad_f<E>(fmaf(ca[j], x8[j], cb[j]));
-              if (store_dg) { dg = Vec16<E>::round(dg); v[j] = dg; }
-              ssum[j] += dg;
-              ssq[j] = fmaf(dg, x8[j], ssq[j]);
+            for (int j = 0; j < CH; j += 2) {           // on pairs: the 16-bit form of GELU' is packed arithmetic
+              const f32x2 gp = gelu_grad_pair<E>(f32x2{fmaf(ca[j], x8[j], cb[j]), fmaf(ca[j + 1], x8[j + 1], cb[j + 1])});
+              float dg0 = Vec16<E>::round(v[j]) * gp.x, dg1 = Vec16<E>::round(v[j + 1]) * gp.y;
+              if (store_dg) { dg0 = Vec16<E>::round(dg0); dg1 = Vec16<E>::round(dg1); v[j] = dg0; v[j + 1] = dg1; }
+              ssum[j] += dg0; ssum[j + 1] += dg1;
+              ssq[j] = fmaf(dg0, x8[j], ssq[j]); ssq[j + 1] = fmaf(dg1, x8[j + 1], ssq[j + 1]);
             }
             if (store_dg) Vec16<E>::store(yg + row_off(it), v);
           } else if (a.stats) {

@@ -582,13 +582,16 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
             if (!store_dg) Vec16<E>::store(yg + off, v);
             float x8[CH];
             Vec16<E>::unpack(bx[it], x8);
+            // (on PAIRS: gelu_grad_f on one element runs the packed 16-bit form on a duplicated pair — the same instructions
+            // for half the work; per lane the arithmetic is the same, so are the results)
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-              const float xh = (x8[j] - bmu[j]) * brs[j];
-              float dg = Vec16<E>::round(v[j]) * gelu_grad_f<E>(bga[j] * xh + bbe[j]);
-              if (store_dg) { dg = Vec16<E>::round(dg); v[j] = dg; }
-              ssum[j] += dg;
-              ssq[j] += dg * xh;
+            for (int j = 0; j < CH; j += 2) {
+              const float xh0 = (x8[j] - bmu[j]) * brs[j], xh1 = (x8[j + 1] - bmu[j + 1]) * brs[j + 1];
+              const f32x2 gp = gelu_grad_pair<E>(f32x2{bga[j] * xh0 + bbe[j], bga[j + 1] * xh1 + bbe[j + 1]});
+              float dg0 = Vec16<E>::round(v[j]) * gp.x, dg1 = Vec16<E>::round(v[j + 1]) * gp.y;
+              if (store_dg) { dg0 = Vec16<E>::round(dg0); dg1 = Vec16<E>::round(dg1); v[j] = dg0; v[j + 1] = dg1; }
+              ssum[j] += dg0; ssum[j + 1] += dg1;
+              ssq[j] += dg0 * xh0; ssq[j + 1] += dg1 * xh1;
             }
             if (store_dg) Vec16<E>::store(yg + off, v);
           } else if (a.stats) {
