@@ -192,6 +192,9 @@ def main():
     backend = os.environ.get("SDA_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if not os.environ.get("SDA_DEFAULT_STREAM"):      # (diagnostic: SDA_DEFAULT_STREAM=1 keeps torch's default stream)
+        from speech_decoding_amd.streams import use_training_stream
+        use_training_stream(dev)                      # the step's chain on a high-priority stream (side streams stay normal)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":

@@ -24,6 +24,11 @@ def step():
     lossf.prefetch(Y, enc.compute_dtype)
     Z = enc(X, subj); loss = lossf(Y, Z); sda_loss.retrieval_ranks(Y, Z)
     opt.zero_grad(set_to_none=True); loss.backward(gradient=one); opt.step()
+# the step's chain on a high-priority stream, as train.py / bench.py run it (speech_decoding_amd/streams.py);
+# SDA_MAIN_PRIO=default keeps torch's default stream, SDA_MAIN_PRIO=0 an explicit normal-priority stream (diagnostic)
+_prio = os.environ.get("SDA_MAIN_PRIO", "-1")
+if _prio != "default":
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(_prio)))
 for _ in range(8): step()
 torch.cuda.synchronize(); gc.collect(); gc.freeze()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 120

@@ -79,6 +79,8 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    from speech_decoding_amd.streams import use_training_stream
+    use_training_stream(device)          # the loop's chain on a high-priority stream; the engine's side streams stay normal
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(os.environ.get("SDA_DIST_BACKEND", "nccl"))
     if args.get("reproducible", False):
