@@ -138,8 +138,11 @@ class EncoderEngine:
                                              # Off: measured 7.10 vs 7.04 ms — like the GLU backward below, the separate pass is
                                              # HBM-bound and runs beside the weight-gradient stream for free; vector work added to an
                                              # MFMA kernel's epilogue takes the matrix pipe's issue slots
+        # (measured twice: with the step on torch's default stream neither paid — 7.15-7.21 vs 7.16 ms; with the step's chain on
+        #  a high-priority stream (streams.py), where a flat kernel gets the CUs it wants when it wants them, the backward pair
+        #  is worth 0.10 ms — 6.77-6.87 vs 6.91-6.92, three alternations — and the forward pair nothing: 6.80-6.87 with both)
         self.flat_1x1_forward = False
-        self.flat_1x1_backward = False
+        self.flat_1x1_backward = True
         self.flat_1x1_options = 0            # extra conv1_flat flags (1024 = staggered tile order, 32768 = one workgroup per CU)
         # CU partition for backward (experiment, default off): k > 0 gives the data-gradient chain (the stream backward() is
         # called on hands over to a CU-masked stream) k of the 8 XCDs and the weight-gradient stream the other 8 - k, instead
