@@ -31,7 +31,7 @@ extern "C" {
 #define SDA_ABI_VERSION 3   /* 2: sda_conv_args gained glu_out / glu_gate, sda_pack_desc gained glu_tile, flag 16384 = SDA_CONV_FLAT_TILES;
                                (still 2, should have been bumped: sda_wgrad_args.acc_scale, new arguments of sda_bn_finalize,
                                sda_clip_logits_stats and sda_clip_grad, new entries sda_clip_dz / sda_param_gemm / sda_copy3d)
-                               3: sda_wgrad_args.flags (SDA_WGRAD_FLAT_ROWS), sda_stream_create_cumask / sda_stream_destroy,
+                               3: sda_wgrad_args.flags (SDA_WGRAD_FLAT_ROWS), sda_stream_create_cumask / sda_stream_create_priority / sda_stream_destroy,
                                conv3_flat takes x_pitch == w_pitch only */
 #define SDA_ROW_PAD 16
 #define SDA_CH_ALIGN 64
@@ -338,6 +338,9 @@ int sda_device_count(void);
  * from THIS thread should size themselves for (0 = the device's; returns the previous limit).  The stream is created in
  * the calling process and destroyed with sda_stream_destroy. */
 int sda_stream_create_cumask(const uint32_t* mask, int nwords, void** stream);
+/* A non-blocking HIP stream of the given priority (hipStreamCreateWithPriority; the device's range on gfx950 is -1 = high,
+ * 0 = normal, 1 = LOW — PyTorch's stream pool offers only the first two).  Out-of-range priorities are an error. */
+int sda_stream_create_priority(int priority, void** stream);
 int sda_stream_destroy(void* stream);
 int sda_set_cu_limit(int cus);
 

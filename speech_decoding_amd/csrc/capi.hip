@@ -64,6 +64,21 @@ extern "C" int sda_stream_create_cumask(const uint32_t* mask, int nwords, void**
   *stream = (void*)st;
   return 0;
 }
+extern "C" int sda_stream_create_priority(int priority, void** stream) {
+  if (!stream) { sda::set_error("stream_create_priority: bad arguments"); return -1; }
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) { sda::set_error("hipDeviceGetStreamPriorityRange: %s", hipGetErrorString(e)); return -2; }
+  if (priority > least || priority < greatest) {
+    sda::set_error("stream_create_priority: %d outside the device's range [%d (high) .. %d (low)]", priority, greatest, least);
+    return -1;
+  }
+  hipStream_t st = nullptr;
+  e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority);
+  if (e != hipSuccess) { sda::set_error("hipStreamCreateWithPriority: %s", hipGetErrorString(e)); return -2; }
+  *stream = (void*)st;
+  return 0;
+}
 extern "C" int sda_stream_destroy(void* stream) {
   if (!stream) return 0;
   const hipError_t e = hipStreamDestroy((hipStream_t)stream);

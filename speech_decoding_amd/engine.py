@@ -114,6 +114,10 @@ class EncoderEngine:
                                              # (needs the fused forward: bufs hold (out, gate)); not with flat-tile data gradients.
                                              # Off: measured 7.87 vs 7.77 ms — the separate pass is HBM-bound and runs beside the
                                              # weight-gradient stream's MFMA work for free, the heavier conv epilogue does not
+        self.tail_products_on_side = True    # composed SubjectBlock backward: the parameter-space products only the optimiser reads
+                                             # (subj_w, sb_w, sb_b) on the weight-gradient stream, off the chain to dz
+        self.subj_wgrad_target_wgs = 0       # workgroups of the PER-SUBJECT weight-gradient launches (0 = wgrad_target_wgs): more
+                                             # slices per subject even out the subjects' unequal sample counts
         self.skip_x0_gradient = True         # composed SubjectBlock: its weight gradient straight from block 0's dh0 and X (kernel-3
                                              # per-subject weight gradient + chain rule) instead of conv0's data gradient + dx0 (x) X
         self.compose_subject_block = True    # SpatialAttention, the shared 1x1 conv and the per-subject 1x1 conv as ONE per-subject
@@ -168,6 +172,14 @@ class EncoderEngine:
             if not isinstance(lit, (bool, int, float)):
                 raise L.SdaError(f"{key}={val!r}: a switch takes a bool, int or float")
             setattr(self, name, lit)
+
+    def _new_side_stream(self, dev) -> torch.cuda.Stream:
+        """The weight-gradient / packing stream: torch's pool for priorities it knows (0 normal, -1 high), the C ABI's
+        stream for HIP's LOW priority (1), which torch.cuda.Stream cannot express."""
+        if self.side_stream_priority <= 0:
+            return torch.cuda.Stream(device=dev, priority=self.side_stream_priority)
+        with torch.cuda.device(dev):
+            return torch.cuda.ExternalStream(ops.stream_create_priority(self.side_stream_priority), device=dev)
 
     @property
     def world(self) -> int:
@@ -316,7 +328,7 @@ class EncoderEngine:
             if self.composed:       # the per-subject gradient is the k = 3 one of (block 0's dh0, X): D2p x 64-channel tiles
                 tm = 160 if d.D2p % 160 == 0 else (128 if d.D2p % 128 == 0 else 64)
                 ntiles = (d.D2p // tm) * (d.Cp // 64)
-            r = int(max(1, min(max(1, B // max(1, d.S)), round(self.wgrad_target_wgs / max(1, ntiles * d.S)))))
+            r = int(max(1, min(max(1, B // max(1, d.S)), round((self.subj_wgrad_target_wgs or self.wgrad_target_wgs) / max(1, ntiles * d.S)))))
             perm, seg = subject_segments(sidx, d.S, r)
             ctx.subj_perm = up("subj_perm", perm, dev)
             ctx.subj_seg = up("subj_seg", seg, dev)
@@ -330,7 +342,7 @@ class EncoderEngine:
         if self.pack_on_side_stream:
             side = self._side.get(str(dev))
             if side is None:
-                side = self._side[str(dev)] = torch.cuda.Stream(device=dev, priority=self.side_stream_priority)
+                side = self._side[str(dev)] = self._new_side_stream(dev)
             composed = self.composed
             Xt = rows("Xt", d.Cp)                # (before the event: a first-use buffer is zero-filled on the MAIN stream)
             ev = torch.cuda.Event()
@@ -581,7 +593,7 @@ class EncoderEngine:
         if self.wgrad_side_stream:
             side = self._side.get(str(dev))
             if side is None:
-                side = self._side[str(dev)] = torch.cuda.Stream(device=dev, priority=self.side_stream_priority)
+                side = self._side[str(dev)] = self._new_side_stream(dev)
 
         def on_side(fn):
             """Run `fn` (launches + allocations) on the side stream once everything queued on the main stream
@@ -633,6 +645,18 @@ class EncoderEngine:
             return on_side(chain)
 
         ntile = B * ops.n_t_tiles(T)
+
+        W0cat = None
+        if ctx.composed is not None and self.skip_x0_gradient:
+            # block 0's conv0 weights as [d][tap][o] (o zero-padded to D2p; the padding is written once), the left operand of the
+            # composed SubjectBlock's gradient at the END of backward: a parameter-only copy, so it is made here, on the
+            # weight-gradient stream while that has nothing to do, not in the serial tail of the step
+            key = ("w0cat", str(dev))
+            W0cat = self._const.get(key)
+            if W0cat is None:
+                W0cat = self._const[key] = torch.zeros((d.D1, 3, d.D2p), dtype=torch.float32, device=dev)
+            _w0 = W0cat
+            on_side(lambda: ops.copy3d(_w0[:, :, : d.D2], P["b0.c0w"].permute(1, 2, 0)))
 
         def dgrad(dy, key, w_fp32, Cout_p, Cin_p, out, KS, dil, res=None, widx=None, bn=None, glu_bwd=None, **glu):
             """Data-gradient conv.  bn = (h, coef): `out` is the gradient entering GELU(BN(h)); the conv's epilogue
@@ -793,11 +817,6 @@ class EncoderEngine:
                                    seg_start=ctx.subj_seg, nseg=r * d.S)     # (r*S, 3, D2p, Cp); column C: the folded bias
                 if r > 1:
                     M = ops.reduce_slabs(M.view(r, -1))
-                key = ("w0cat", str(dev))
-                W0cat = self._const.get(key)             # [d][tap][o], o zero-padded to D2p (the padding is written once)
-                if W0cat is None:
-                    W0cat = self._const[key] = torch.zeros((d.D1, 3, d.D2p), dtype=torch.float32, device=dev)
-                ops.copy3d(W0cat[:, :, : d.D2], P["b0.c0w"].permute(1, 2, 0))
                 G = ops.param_gemm(W0cat.view(d.D1, 3 * d.D2p), M.view(d.S, 3 * d.D2p, d.Cp)[:, :, : d.C + 1])   # (S, D1, C + 1)
             else:
                 slabs = ops.wgrad_gemm(dhs, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg,
@@ -805,12 +824,16 @@ class EncoderEngine:
                 if r > 1:
                     slabs = ops.reduce_slabs(slabs.view(r, -1))
                 G = slabs.view(d.S, d.D1p, d.Cp)[:, : d.D1, : d.C + 1]                            # (S, D1, C + 1) view
-            grads["subj_w"] = ops.param_gemm(G, T1aug.t()).view(d.S, d.D1, d.D1, 1)            # W_tot[s] = W_subj[s] T1aug
+            # The chain to the last gradient of the step is M -> G -> W_subj^T G -> dT1 -> dWd -> dz; the products that only
+            # the optimiser reads (subj_w, sb_w, sb_b) leave it for the weight-gradient stream (tail_products_on_side)
+            off_chain = on_side if self.tail_products_on_side else (lambda fn: fn())
+            grads["subj_w"] = off_chain(lambda: ops.param_gemm(G, T1aug.t()).view(d.S, d.D1, d.D1, 1))   # W_tot[s] = W_subj[s] T1aug
             part = ops.param_gemm(Ws.transpose(1, 2), G)                                         # W_subj[s]^T G[s] per subject ...
-            dT1 = ops.reduce_slabs(part.view(d.S, -1)).view(d.D1, d.C + 1)                       # ... summed in subject order
-            grads["sb_b"] = ops.copy3d(torch.empty(d.D1, dtype=torch.float32, device=dev), dT1[:, d.C])
-            dT1 = dT1[:, : d.C]
-            grads["sb_w"] = ops.param_gemm(dT1, Wd.t()).unsqueeze(-1)
+            dT1f = ops.reduce_slabs(part.view(d.S, -1)).view(d.D1, d.C + 1)                      # ... summed in subject order
+            dT1 = dT1f[:, : d.C]
+            grads["sb_b"], grads["sb_w"] = off_chain(lambda: (
+                ops.copy3d(torch.empty(d.D1, dtype=torch.float32, device=dev), dT1f[:, d.C]),
+                ops.param_gemm(dT1, Wd.t()).unsqueeze(-1)))
             dWd = ops.param_gemm(P["sb_w"][..., 0].t(), dT1)
             grads["z"] = ops.sa_weights_backward(dWd, ctx.W_sa, ctx.mask, P["cosT"], P["sinT"], P["z"].shape[1],
                                                  bwd_table=P.get("sa_tab_b"))

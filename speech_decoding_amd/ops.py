@@ -37,6 +37,14 @@ def stream_create_cumask(words) -> int:
     return int(out.value)
 
 
+def stream_create_priority(priority: int) -> int:
+    """A non-blocking HIP stream of `priority` (-1 high, 0 normal, 1 LOW: the last is below anything torch's stream pool
+    hands out); returns the hipStream_t as an integer for torch.cuda.ExternalStream.  Never destroyed (one per device)."""
+    out = C.c_void_p()
+    L.check(L.load().sda_stream_create_priority(int(priority), C.byref(out)), "stream_create_priority")
+    return int(out.value)
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:

@@ -8,7 +8,13 @@ import numpy as np
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ad = [i for i, r in enumerate(rows) if "adam_multi" in r["Kernel_Name"]]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else -8      # a steady-state step of the timed region (the last ones are instrumented)
+# which step: the given index, or by default the SHORTEST of the timed region's steps (the last ones are instrumented, and under
+# the profiler the host stalls for milliseconds every few steps — a step with such a hole says nothing about the schedule)
+if len(sys.argv) > 2 and sys.argv[2] not in ("", "auto"):
+    k = int(sys.argv[2])
+else:
+    cand = range(max(1, len(ad) - 16), len(ad) - 4)
+    k = min(cand, key=lambda i: int(rows[ad[i]]["End_Timestamp"]) - int(rows[ad[i - 1] + 1]["Start_Timestamp"])) - len(ad)
 lo, hi = ad[k - 1] + 1, ad[k] + 1
 t0, t1 = int(rows[lo]["Start_Timestamp"]), int(rows[hi - 1]["End_Timestamp"])
 print(f"step span {(t1 - t0) / 1e3:.1f} us, {hi - lo} kernels")
@@ -38,3 +44,8 @@ for s, e, q, n in ks:
 print("family: launches, total us, of which beside another stream's kernel")
 for n, (c, tot, ov) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:22]:
     print(f"   {n:46s} {c:3d} {tot:8.0f} {ov:8.0f}")
+# full listing (optional third argument "list"): every kernel of the step in start order — start, duration, stream, name
+if len(sys.argv) > 3 and sys.argv[3] == "list":
+    print("listing: start us, duration us, stream, kernel")
+    for s, e, q, n in ks:
+        print(f"   {s / 1e3:8.1f} {(e - s) / 1e3:7.1f}  s{q}  {n}")
