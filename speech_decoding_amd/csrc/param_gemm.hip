@@ -12,9 +12,9 @@
 // One workgroup = 4 waves (2 x 2) owns a TM x TM tile (TM = 128 or 64) of one batch member; the contraction runs in
 // steps of 16 through LDS images stored k-major ([k][i], [k][j]) so that the operand of v_mfma_f32_16x16x4_f32 — lane
 // l supplies A[i = l & 15][k = l >> 4] resp. B[k = l >> 4][j = l & 15] — is one conflict-free ds_read_b32.  Global
-// loads are per-element with bounds checks (zero fill), coalesced along whichever index has the unit stride, and the
-// loads of step s + 1 are in registers while step s computes.  fp32 throughout: results are a k-ordered fmaf chain
-// per output element, bitwise reproducible.  Bound: fp32 matrix rate (157 TFLOP/s); these products are ~6 GFLOP a
+// loads are per-element (rows / columns outside the operand clamped, the contraction's tail zero-filled), coalesced along
+// whichever index has the unit stride, and the loads of step s + 1 are in registers while step s computes.  fp32 throughout:
+// results are a k-ordered fmaf chain per output element, bitwise reproducible.  Bound: fp32 matrix rate (157 TFLOP/s); these products are ~6 GFLOP a
 // step, i.e. tens of microseconds.
 #include "sd_common.h"
 
@@ -26,6 +26,7 @@ constexpr int PG_K = 16;                 // contraction step
 
 template <int TM> struct PGeom {
   static constexpr int PITCH = TM + 4;   // floats per LDS row; +4 keeps the k-major stores of the k-fastest load pattern spread
+                                         // (+16, conflict-free fragment reads at 4-way store conflicts: the same 75 us)
   static constexpr int FR = TM / 32;     // 16x16 fragments per wave and dimension (wave tile TM/2 x TM/2)
   static constexpr int PER_THREAD = TM * PG_K / 256;      // elements of one operand tile per thread and step
 };
@@ -63,33 +64,44 @@ __global__ __launch_bounds__(256) void param_gemm_kernel(const sda_pgemm_args a)
     if (b_kfast) { kk = idx % PG_K; r = idx / PG_K; } else { r = idx % TM; kk = idx / TM; }
   };
   float ra[G::PER_THREAD], rb[G::PER_THREAD];
-  // per element: its address at step 0 and whether its row / column exists — a step then costs one compare, one load and one
-  // pointer bump per element (the address arithmetic of a naive fetch, 64-bit multiplies included, outweighed the MFMAs)
-  const float* pa[G::PER_THREAD];
-  const float* pb[G::PER_THREAD];
-  int ka[G::PER_THREAD], kb[G::PER_THREAD];                 // the element's k inside a step, or a value that never passes the test
+  // per element: its 32-bit byte offset from a wave-uniform base that one scalar add advances per step (the host checked
+  // that every offset fits) — a full step then costs one load and one 64-bit add per element: with per-element
+  // 64-bit pointers, a bounds compare and a pointer bump each, the fetch was 3.6 vector instructions per MFMA on the port the
+  // MFMAs issue through (profiles/r04_step_sq_counters.txt).  Rows / columns outside the operand are CLAMPED, not zero-filled:
+  // they feed outputs that are never stored.  Only the contraction's partial last step (k >= K must contribute zero) tests.
+  uint32_t oa[G::PER_THREAD], ob[G::PER_THREAD];
+  int ka[G::PER_THREAD], kb[G::PER_THREAD];                 // the element's k inside a step
 #pragma unroll
   for (int e = 0; e < G::PER_THREAD; ++e) {
     int r, kk;
     a_coord(e, r, kk);
-    const bool ok_a = i0 + r < a.M;
-    pa[e] = Ab + (size_t)(ok_a ? i0 + r : 0) * a.a_i + (size_t)kk * a.a_k;
-    ka[e] = ok_a ? kk : 0x40000000;
+    oa[e] = (uint32_t)(((long)min(i0 + r, a.M - 1) * a.a_i + (long)kk * a.a_k) * 4);      // BYTES: global_load saddr + 32-bit voffset
+    ka[e] = kk;
     b_coord(e, r, kk);
-    const bool ok_b = j0 + r < a.N;
-    pb[e] = Bb + (size_t)kk * a.b_k + (size_t)(ok_b ? j0 + r : 0) * a.b_j;
-    kb[e] = ok_b ? kk : 0x40000000;
+    ob[e] = (uint32_t)(((long)kk * a.b_k + (long)min(j0 + r, a.N - 1) * a.b_j) * 4);
+    kb[e] = kk;
   }
-  const size_t step_a = (size_t)PG_K * a.a_k, step_b = (size_t)PG_K * a.b_k;
+  const long step_a = (long)PG_K * a.a_k, step_b = (long)PG_K * a.b_k;
+  const char* __restrict__ Ak = reinterpret_cast<const char*>(Ab);      // wave-uniform: base of the step being fetched
+  const char* __restrict__ Bk = reinterpret_cast<const char*>(Bb);
+  auto ld = [](const char* base, uint32_t off) { return *reinterpret_cast<const float*>(base + off); };
   auto fetch = [&](int k0) {
     const int left = a.K - k0;
+    if (left >= PG_K) {
 #pragma unroll
-    for (int e = 0; e < G::PER_THREAD; ++e) {
-      ra[e] = ka[e] < left ? *pa[e] : 0.f;
-      rb[e] = kb[e] < left ? *pb[e] : 0.f;
-      pa[e] += step_a;
-      pb[e] += step_b;
+      for (int e = 0; e < G::PER_THREAD; ++e) {
+        ra[e] = ld(Ak, oa[e]);
+        rb[e] = ld(Bk, ob[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < G::PER_THREAD; ++e) {
+        ra[e] = ka[e] < left ? ld(Ak, oa[e]) : 0.f;
+        rb[e] = kb[e] < left ? ld(Bk, ob[e]) : 0.f;
+      }
     }
+    Ak += step_a * 4;
+    Bk += step_b * 4;
   };
   auto stash = [&]() {
 #pragma unroll
@@ -108,6 +120,8 @@ __global__ __launch_bounds__(256) void param_gemm_kernel(const sda_pgemm_args a)
 #pragma unroll
     for (int n = 0; n < G::FR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // (a register ring of four steps' loads, statically indexed, was tried: hipcc's own s_waitcnt in front of each stash came
+  // out as vmcnt(8) — only the step fetched last may stay in flight — so the effective distance stayed one step: 75 us either way)
   fetch(0);
   for (int k0 = 0; k0 < a.K; k0 += PG_K) {
     __syncthreads();                       // the previous step's LDS reads are done
@@ -170,6 +184,13 @@ extern "C" int sda_param_gemm(const sda_pgemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) { set_error("param_gemm: null argument"); return -1; }
   if (a->M < 1 || a->N < 1 || a->K < 1 || a->batch < 1) { set_error("param_gemm: empty problem"); return -1; }
   if (a->c_dtype != SDA_F32 && a->c_dtype != SDA_BF16 && a->c_dtype != SDA_F16) { set_error("param_gemm: unknown output dtype %d", a->c_dtype); return -1; }
+  // the kernel addresses an operand by 32-bit element offsets from a per-batch-member base (parameter-sized by contract)
+  auto span = [](long n0, long s0, long n1, long s1) { return (n0 - 1) * (s0 < 0 ? -s0 : s0) + (n1 - 1) * (s1 < 0 ? -s1 : s1); };
+  if (a->a_i < 0 || a->a_k < 0 || a->b_k < 0 || a->b_j < 0) { set_error("param_gemm: negative strides are not supported"); return -1; }
+  if (span(a->M, a->a_i, a->K, a->a_k) > 0x3fffffffL || span(a->K, a->b_k, a->N, a->b_j) > 0x3fffffffL) {
+    set_error("param_gemm: an operand spans more than 2^30 elements per batch member (parameter-sized operands only)");
+    return -1;
+  }
   const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
   if ((long)((a->M + 63) / 64) * ((a->N + 63) / 64) * a->batch > 0x7fffffffL) { set_error("param_gemm: grid too large"); return -1; }
   // 128-wide tiles once they fill the chip; 64-wide ones otherwise (four times the workgroups for the same work)
