@@ -31,7 +31,7 @@ extern "C" {
 #define SDA_ABI_VERSION 3   /* 2: sda_conv_args gained glu_out / glu_gate, sda_pack_desc gained glu_tile, flag 16384 = SDA_CONV_FLAT_TILES;
                                (still 2, should have been bumped: sda_wgrad_args.acc_scale, new arguments of sda_bn_finalize,
                                sda_clip_logits_stats and sda_clip_grad, new entries sda_clip_dz / sda_param_gemm / sda_copy3d)
-                               3: sda_wgrad_args.flags (SDA_WGRAD_FLAT_ROWS), sda_stream_create_cumask / sda_stream_create_priority / sda_stream_destroy,
+                               3: sda_wgrad_args.flags (SDA_WGRAD_FLAT_ROWS), sda_stream_create_cumask / sda_stream_create_priority / sda_stream_destroy, sda_sim_gemm / sda_sim_gemm_ksplit,
                                conv3_flat takes x_pitch == w_pitch only */
 #define SDA_ROW_PAD 16
 #define SDA_CH_ALIGN 64
@@ -282,6 +282,15 @@ typedef struct sda_wgrad_args {
 int sda_wgrad_gemm(const sda_wgrad_args* a, void* stream);
 /* dst[i] = sum_s src[s][i] in fixed order */
 int sda_reduce_slabs(const float* src, float* dst, int nslabs, long n, void* stream);
+/* The loss's similarity matmul (loss.py:68) on 256 x 256 output tiles, 16-bit storage (csrc/sim_gemm.hip):
+ *     partial[ks][i][j] = sum_{k in K slice ks} X[i][k] * W[j][k],   i < M, j < Np, ks < ksplit      (fp32)
+ * X (M rows) and W (N rows) are K-contiguous rows `pitch` elements apart (K % 32 == 0, 16-byte aligned); columns [N, Np) are
+ * don't-care.  The caller sums the K slices with sda_reduce_slabs (fixed order).  sda_sim_gemm_ksplit returns the number of
+ * K slices to launch with for this shape on the current device, 0 if the shape is not served (fp32 storage: use sda_conv_gemm's
+ * split-K matrix mode). */
+int sda_sim_gemm_ksplit(int M, int N, long K, int dtype);
+int sda_sim_gemm(const void* X, const void* W, float* partial, int M, int N, int Np, long K, long pitch, int ksplit, int dtype,
+                 void* stream);
 
 /* SpatialAttention weights (models.py:49-58 with SpatialDropout 81-84 folded in):
  * a = Re(z) cos + Im(z) sin; W = softmax_c(a); Wd = W * mask.  z is complex64 interleaved (re, im).

@@ -62,6 +62,8 @@ SIGNATURES = {
     "sda_pad_channels": (i32, [i32]),
     "sda_device_count": (i32, []),
     "sda_stream_create_cumask": (i32, [vp, i32, vp]),
+    "sda_sim_gemm_ksplit": (i32, [i32, i32, i64, i32]),
+    "sda_sim_gemm": (i32, [vp, vp, vp, i32, i32, i32, i64, i64, i32, i32, vp]),
     "sda_stream_create_priority": (i32, [i32, vp]),
     "sda_stream_destroy": (i32, [vp]),
     "sda_set_cu_limit": (i32, [i32]),

@@ -3,6 +3,7 @@ memory and the current HIP stream; every computation happens inside libsdamd.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -422,10 +423,26 @@ def conv_stats_rows(B: int, T: int, KS: int, Cout_p: int, flags: int = 0) -> int
     return L.load().sda_conv_stats_rows(B, T, KS, Cout_p, flags)
 
 
+# the similarity matmul of 16-bit operands on sim_gemm.hip's 256 x 256 tiles (SDA_SIM_GEMM=0: conv_gemm's split-K matrix mode
+# with 128 x 128 tiles, which fp32 storage always uses)
+SIM_GEMM_TILES256 = os.environ.get("SDA_SIM_GEMM", "1") != "0"
+
+
 def matmul_nt_splitk(xm: torch.Tensor, wm: torch.Tensor, M: int, N: int, K: int, pitch: int) -> torch.Tensor:
     """S[i][j] = sum_k xm[i][k] * wm[j][k] (both K-contiguous rows with `pitch`), fp32 (M, pad64(N)) result.
     Runs conv_gemm in split-K mode + ordered slab reduction (loss.py:68)."""
     Np = L.pad_channels(N)
+    if SIM_GEMM_TILES256 and K <= pitch:
+        # 16-bit storage: 256 x 256 output tiles, every operand byte of a K slice through LDS once (csrc/sim_gemm.hip)
+        ks = L.load().sda_sim_gemm_ksplit(M, N, K, dt_code(xm.dtype))
+        if ks > 0:
+            partial = torch.empty((ks, M, Np), dtype=torch.float32, device=xm.device)
+            L.check(L.load().sda_sim_gemm(_p(xm), _p(wm), _p(partial), M, N, Np, K, pitch, ks, dt_code(xm.dtype), _st()), "sim_gemm")
+            if ks == 1:
+                return partial[0]
+            out = torch.empty((M, Np), dtype=torch.float32, device=xm.device)
+            L.check(L.load().sda_reduce_slabs(_p(partial), _p(out), ks, M * Np, _st()), "reduce_slabs")
+            return out
     slab = 32 if xm.dtype == torch.float32 else 64
     nslab = K // slab
     tile_co = 160 if Np % 160 == 0 else (128 if Np % 128 == 0 else 64)

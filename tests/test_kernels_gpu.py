@@ -729,3 +729,34 @@ def test_clip_dz_streaming_kernel_against_fp64(ops, Bm, Bn, F, T, dtype):
     for b in range(Bn):                                                   # pad rows come out as exact zeros, pad channels too
         assert float(full[b * Tp: b * Tp + L.ROW_PAD].abs().max()) == 0.0
     assert float(full[:, F:].abs().max()) == 0.0 if full.shape[1] > F else True
+
+
+# -----------------------------------------------------------------------------------------------
+# the similarity matmul on 256 x 256 tiles (csrc/sim_gemm.hip; loss.py:68): against fp64 on the SAME 16-bit operands (the only
+# rounding left is the fp32 accumulation order), ragged row counts on both sides (rows past the operands are clamped), a
+# row pitch larger than the contraction, and bit-equal repeats (the K slices are summed in fixed order)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,pitch", [(256, 256, 16384, 16384), (300, 200, 4096, 4096 + 64), (64, 24, 2048, 2048), (2048, 256, 8192, 8192),
+                                         (513, 257, 1024, 1024)])
+def test_sim_gemm_256_tiles_against_fp64(ops, dtype, M, N, K, pitch):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N)
+    X = torch.randn(M, pitch, device=DEV, generator=g).to(dtype)
+    W = torch.randn(N, pitch, device=DEV, generator=g).to(dtype)
+    assert ops.SIM_GEMM_TILES256 and L.load().sda_sim_gemm_ksplit(M, N, K, ops.dt_code(dtype)) > 0
+    S = ops.matmul_nt_splitk(X, W, M, N, K, pitch)
+    assert S.shape == (M, L.pad_channels(N)) and S.dtype == torch.float32
+    ref = X[:, :K].double() @ W[:, :K].double().t()
+    err = (S[:, :N].double() - ref).abs().max().item()
+    assert err <= 2e-5 * math.sqrt(K) * 4, err            # fp32 accumulation of K products of O(1) terms
+    again = ops.matmul_nt_splitk(X, W, M, N, K, pitch)
+    assert torch.equal(S[:, :N], again[:, :N])
+    # the fp32 storage type is not served by this kernel: the split-K matrix mode of conv_gemm takes it
+    assert L.load().sda_sim_gemm_ksplit(M, N, K, ops.dt_code(torch.float32)) == 0
+    # and equals conv_gemm's split-K matrix mode within the accumulation order
+    ops.SIM_GEMM_TILES256 = False
+    try:
+        old = ops.matmul_nt_splitk(X, W, M, N, K, pitch)
+    finally:
+        ops.SIM_GEMM_TILES256 = True
+    assert (old[:, :N] - S[:, :N]).abs().max().item() <= 2e-5 * math.sqrt(K) * 4
