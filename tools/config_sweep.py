@@ -5,9 +5,11 @@ import torch
 from speech_decoding_amd.layout import synthetic_positions
 from speech_decoding_amd import BrainEncoder, CLIPLoss, load_config
 from speech_decoding_amd.optim import FusedAdam
+from speech_decoding_amd.streams import use_training_stream
 
 def run(name, C, S, T, B, F=1024, dtype="bf16", steps=8):
     dev = "cuda:0"
+    use_training_stream(dev)             # the step's chain on a high-priority stream, as bench.py / train.py run it
     cfg = load_config(overrides=[f"num_subjects={S}", f"compute_dtype={dtype}"])
     cfg["sensor_positions"] = synthetic_positions(C, 0).numpy()
     with warnings.catch_warnings():
