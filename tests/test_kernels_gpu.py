@@ -760,3 +760,16 @@ def test_sim_gemm_256_tiles_against_fp64(ops, dtype, M, N, K, pitch):
     finally:
         ops.SIM_GEMM_TILES256 = True
     assert (old[:, :N] - S[:, :N]).abs().max().item() <= 2e-5 * math.sqrt(K) * 4
+
+
+def test_priority_stream_entry_point(ops):
+    """sda_stream_create_priority: the three HIP priorities give usable streams (a kernel runs on each), anything else is an error."""
+    from speech_decoding_amd import lib as L
+    for prio in (-1, 0, 1):
+        st = torch.cuda.ExternalStream(ops.stream_create_priority(prio), device=DEV)
+        with torch.cuda.stream(st):
+            t = ops.upload_small(np.arange(7, dtype=np.int32), DEV)
+        st.synchronize()
+        assert t.cpu().tolist() == list(range(7))
+    with pytest.raises(L.SdaError):
+        ops.stream_create_priority(5)
