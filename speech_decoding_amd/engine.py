@@ -101,6 +101,9 @@ class EncoderEngine:
         self.forward_pair_tiles = True       # forward k = 3 convs (nothing competes for the CU's LDS there): two
                                              # tiles per workgroup share each weight slab — fewer LDS-DMA bytes per FLOP
         self.flat_tiles_forward = True       # k = 3 convs on the 256-row flat-tile kernel (conv3_flat.hip) where it applies
+        self.flat_tiles_forward_fp32 = False # ... for fp32 storage as well.  Off: conv3_flat's K loop (rebuilt in round 4 around the
+                                             # 16-bit kernels' register budget) spills ~300 registers in its fp32 instantiation —
+                                             # the exact path's step is 46.3 ms with it, 35.6 ms on the tile kernel (same box)
         self.flat_tile_options = 1024        # extra conv3_flat flags: 1024 = the second workgroup of a CU takes its 128-row tile FIRST
                                              # (the pair's epilogues — HBM bursts with the matrix pipe idle — fall at different
                                              # times: 68.6 -> 67.3 us per 320 -> 320 conv with the priority hand-over, round 4),
@@ -240,7 +243,12 @@ class EncoderEngine:
 
     @property
     def glu_fused(self) -> bool:
-        return bool(self.fuse_glu_forward and self.flat_tiles_forward and self.d.D2p % 80 == 0)
+        return bool(self.fuse_glu_forward and self.flat_forward and self.d.D2p % 80 == 0)
+
+    @property
+    def flat_forward(self) -> bool:
+        """Forward k = 3 convs on conv3_flat.hip: the 16-bit storage types; fp32 only on request (flat_tiles_forward_fp32)."""
+        return bool(self.flat_tiles_forward and (self.dtype != torch.float32 or self.flat_tiles_forward_fp32))
 
     def _wait(self, label: str, stream, event):
         """stream.wait_event(event); with a probe attached, bracketed by timing events (how long the stream sat idle)."""
@@ -368,7 +376,7 @@ class EncoderEngine:
             Xt = rows("Xt", d.Cp)
             ops.pack_rows(X, Xt, ones_channel=d.C if composed else None)
         k3_flags = L.CONV_PAIR_TILES if self.forward_pair_tiles else 0
-        if self.flat_tiles_forward:
+        if self.flat_forward:
             k3_flags |= L.CONV_FLAT_TILES | self.flat_tile_options
 
         # ---- SubjectBlock (models.py:111-117)
