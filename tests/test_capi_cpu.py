@@ -124,3 +124,33 @@ def test_oracle_is_imported_only_by_the_checkers():
     assert len(hits) == 1
     head = bench[: hits[0]]
     assert head.rfind("def cpu_baseline") > head.rfind("\ndef main"), "bench.py: oracle import outside cpu_baseline()"
+
+
+def test_no_kernel_of_the_library_spills_heavily(tmp_path):
+    """Register spills inside a K loop cost a third of a kernel's speed and look like box-to-box noise in a step time (round 4:
+    conv3_flat's rebuilt K loop spilled ~300 registers in its fp32 instantiation for half a round before anyone looked).  Reads
+    the gfx950 code objects' metadata out of the built library: every kernel stays under 64 spilled registers, except the
+    instantiations listed here — which no default path launches (engine.flat_tiles_forward_fp32 = False)."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    so = os.path.join(ROOT, "speech_decoding_amd", "libsdamd.so")
+    if not (os.path.exists(os.path.join(llvm, "llvm-objdump")) and os.path.exists(so)):
+        pytest.skip("needs the ROCm LLVM tools and the built library")
+    work = tmp_path / "co"
+    work.mkdir()
+    shutil.copy(so, work / "libsdamd.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", "libsdamd.so"], cwd=work, check=True, capture_output=True)
+    objs = [f for f in os.listdir(work) if "gfx950" in f]
+    assert objs, "no gfx950 code object in the library"
+    known = re.compile(r"conv3_flat_kernelIf")          # fp32 storage on the flat-tile kernel: off every default path
+    seen, bad = 0, []
+    for f in objs:
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", f], cwd=work, check=True, capture_output=True, text=True).stdout
+        for name, spill in re.findall(r"\.name:\s+(\S+)\n\s+(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", notes):
+            seen += 1
+            if int(spill) >= 64 and not known.search(name):
+                bad.append((name, int(spill)))
+    assert seen > 100, seen                             # the library holds a few hundred instantiations
+    assert not bad, bad
