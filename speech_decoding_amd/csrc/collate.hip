@@ -3,8 +3,10 @@
 // (preproc_utils.py:128-142) + scaleAndClamp (preproc_utils.py:69-90): for every (sample, channel) row of T
 // samples subtract the mean of the first `nb` samples, then RobustScaler (sklearn: centre = median, scale =
 // 75th - 25th percentile with linear interpolation, zero scale -> 1) over time, then clamp to +-lim.
-// One wavefront per row: the row is sorted in LDS (bitonic, padded with +inf) to read the three quantiles.
+// One wavefront per row: the row is sorted in registers (bitonic over registers x lanes, padded with +inf) and laid out
+// in LDS once to read the three quantiles.
 #include "sd_common.h"
+#include "flat_tile.h"
 
 namespace sda {
 
@@ -16,6 +18,8 @@ __global__ __launch_bounds__(256) void collate_rows_kernel(const float* __restri
                                                            float* __restrict__ dst, long rows, int T, int nb, float lim,
                                                            int do_clamp) {
   constexpr int N = 64 * NPL;
+  constexpr int LOG2N = NPL == 8 ? 9 : 10;
+  static_assert((1 << LOG2N) == N, "NPL is 8 or 16");
   __shared__ float sbuf[4][N];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wid;
@@ -24,36 +28,80 @@ __global__ __launch_bounds__(256) void collate_rows_kernel(const float* __restri
   const long r = live ? row : 0;
   const float* x = win_ptr ? win_ptr[r / C] + (r % C) * win_cstride[r / C] : src + r * T;
 
+  // Element t of the row lives in register t % NPL of lane t / NPL (a lane holds NPL CONSECUTIVE samples: 16-byte global
+  // accesses where the row allows them).
   float v[NPL];
+  const bool vec = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+  if (vec) {
+#pragma unroll
+    for (int q = 0; q < NPL / 4; ++q) {
+      const int t = lane * NPL + 4 * q;
+      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < T) f = *reinterpret_cast<const float4*>(x + t);
+      v[4 * q + 0] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int t = lane * NPL + i;
+      v[i] = (t < T) ? x[t] : 0.f;
+    }
+  }
   float bsum = 0.f;
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
-    const int t = lane + 64 * i;
-    v[i] = (t < T) ? x[t] : 0.f;
-    if (t < nb) bsum += v[i];
+    if (lane * NPL + i < nb) bsum += v[i];
   }
   const float base = nb > 0 ? wave_sum(bsum) / (float)nb : 0.f;
+  // Bitonic sort of the wave's 64 * NPL values IN REGISTERS (padding = +inf).  A compare-exchange at distance j < NPL pairs
+  // two registers of one lane; at j >= NPL lane l with lane l ^ (j / NPL): a DPP quad permutation for lane distances 1 and
+  // 2 (no LDS involved), one ds_bpermute per register beyond.  For 512 values: 24 of the 45 stages stay inside the lane,
+  // 11 are DPP, 10 go through the LDS crossbar (80 ds_bpermute per row).  History (config 2, 256 x 208 rows of 360):
+  // an LDS image with a workgroup barrier per stage 264 us; registers with lane-major elements (39 crossbar stages) 204 us.
+  float w[NPL];
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
-    const int t = lane + 64 * i;
     v[i] -= base;
-    s[t] = (t < T) ? v[i] : INFINITY;
+    w[i] = (lane * NPL + i < T) ? v[i] : INFINITY;
   }
-  __syncthreads();
-  for (int k = 2; k <= N; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
+  auto xor_lane = [&](float val, auto dc) -> float {
+    constexpr int d = decltype(dc)::value;                  // lane distance (a power of two below 64)
+    const int iv = __float_as_int(val);
+    if constexpr (d == 1) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    else if constexpr (d == 2) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    else return __shfl_xor(val, d);
+  };
+  static_for<1, LOG2N + 1>([&](auto kc) {
+    constexpr int k = 1 << decltype(kc)::value;
+    static_for<0, decltype(kc)::value>([&](auto jc) {
+      constexpr int j = k >> (decltype(jc)::value + 1);
+      if constexpr (j < NPL) {
 #pragma unroll
-      for (int i = 0; i < NPL / 2; ++i) {
-        const int p = lane + 64 * i;                       // pair index 0 .. N/2-1
-        const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-        const int hi = lo | j;
-        const bool up = (lo & k) == 0;
-        const float a = s[lo], b = s[hi];
-        if ((a > b) == up) { s[lo] = b; s[hi] = a; }
+        for (int i = 0; i < NPL; ++i) {
+          if ((i & j) == 0) {
+            // direction: bit k of the element index lane * NPL + i
+            const bool up = k < NPL ? ((i & k) == 0) : (((lane * NPL) & k) == 0);
+            const float a = w[i], b = w[i | j];
+            const float lo = fminf(a, b), hi = fmaxf(a, b);
+            w[i] = up ? lo : hi;
+            w[i | j] = up ? hi : lo;
+          }
+        }
+      } else {
+        constexpr int d = j / NPL;
+        const bool take_min = ((lane & d) == 0) == (((lane * NPL) & k) == 0);     // lower element of an ascending pair, or upper of a descending one
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          const float p = xor_lane(w[i], std::integral_constant<int, d>{});
+          w[i] = take_min ? fminf(w[i], p) : fmaxf(w[i], p);
+        }
       }
-      __syncthreads();
-    }
-  }
+    });
+  });
+  // the sorted row, once, for the three quantile reads (same wave writes and reads: the barrier only orders them)
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) s[lane * NPL + i] = w[i];
+  __syncthreads();
   auto quantile = [&](float q) {
     const float pos = q * (float)(T - 1);
     const int i0 = (int)floorf(pos);
@@ -66,13 +114,23 @@ __global__ __launch_bounds__(256) void collate_rows_kernel(const float* __restri
   if (iqr == 0.f) iqr = 1.f;                               // sklearn _handle_zeros_in_scale
   if (live) {
     float* y = dst + row * T;
+    float o[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-      const int t = lane + 64 * i;
-      if (t < T) {
-        float o = (v[i] - med) / iqr;
-        if (do_clamp) o = fminf(fmaxf(o, -lim), lim);
-        y[t] = o;
+      o[i] = (v[i] - med) / iqr;
+      if (do_clamp) o[i] = fminf(fmaxf(o[i], -lim), lim);
+    }
+    if (vec) {
+#pragma unroll
+      for (int q = 0; q < NPL / 4; ++q) {
+        const int t = lane * NPL + 4 * q;
+        if (t < T) *reinterpret_cast<float4*>(y + t) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int t = lane * NPL + i;
+        if (t < T) y[t] = o[i];
       }
     }
   }
