@@ -53,48 +53,70 @@ __global__ __launch_bounds__(256) void collate_rows_kernel(const float* __restri
     if (lane * NPL + i < nb) bsum += v[i];
   }
   const float base = nb > 0 ? wave_sum(bsum) / (float)nb : 0.f;
-  // Bitonic sort of the wave's 64 * NPL values IN REGISTERS (padding = +inf).  A compare-exchange at distance j < NPL pairs
-  // two registers of one lane; at j >= NPL lane l with lane l ^ (j / NPL): a DPP quad permutation for lane distances 1 and
-  // 2 (no LDS involved), one ds_bpermute per register beyond.  For 512 values: 24 of the 45 stages stay inside the lane,
-  // 11 are DPP, 10 go through the LDS crossbar (80 ds_bpermute per row).  History (config 2, 256 x 208 rows of 360):
-  // an LDS image with a workgroup barrier per stage 264 us; registers with lane-major elements (39 crossbar stages) 204 us.
+  // Bitonic sort of the wave's 64 * NPL values IN REGISTERS (padding = +inf).  A compare-exchange at distance < NPL pairs
+  // two registers of one lane; beyond, lane l with another lane: DPP (quad permutations, row_half_mirror, row_mirror: no
+  // LDS involved) for lane masks 1, 2, 3, 7, 15, one ds_bpermute per register otherwise.  For 512 values: 24 of the 45
+  // stages stay inside the lane, 13 are DPP, 8 go through the LDS crossbar.  History (config 2, 256 x 208 rows of 360): an
+  // LDS image with a workgroup barrier per stage 264 us; registers with lane-major elements (39 crossbar stages) 204 us;
+  // lane-contiguous elements with per-pair direction selects 135 us.
   float w[NPL];
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     v[i] -= base;
     w[i] = (lane * NPL + i < T) ? v[i] : INFINITY;
   }
-  auto xor_lane = [&](float val, auto dc) -> float {
-    constexpr int d = decltype(dc)::value;                  // lane distance (a power of two below 64)
+  // The network is the all-ascending form of the bitonic sort: merge step k first compares element e with e ^ (k - 1) (its
+  // mirror image inside the k-block), then with e ^ j for j = k / 4 ... 1 — the element with the lower index always keeps
+  // the minimum, so there is no direction to select.  Inside a lane that is v_min + v_max per pair; between lanes ONE
+  // v_med3_f32 per register against a per-lane constant (-inf in the lower lane: med3(a, b, -inf) = min; +inf in the upper).
+  auto shuffle = [&](float val, auto mc) -> float {          // the value of lane (lane ^ m), m = 2^n - 1 (mirror) or a power of two
+    constexpr int m = decltype(mc)::value;
     const int iv = __float_as_int(val);
-    if constexpr (d == 1) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-    else if constexpr (d == 2) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-    else return __shfl_xor(val, d);
+    if constexpr (m == 1) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false));        // quad_perm [1,0,3,2]
+    else if constexpr (m == 2) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    else if constexpr (m == 3) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0x1B, 0xF, 0xF, false));   // quad_perm [3,2,1,0]
+    else if constexpr (m == 7) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    else if constexpr (m == 15) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0x140, 0xF, 0xF, false)); // row_mirror
+    else return __shfl_xor(val, m);
   };
   static_for<1, LOG2N + 1>([&](auto kc) {
     constexpr int k = 1 << decltype(kc)::value;
-    static_for<0, decltype(kc)::value>([&](auto jc) {
+    // --- mirror step: e <-> e ^ (k - 1)
+    if constexpr (k <= NPL) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        if ((i & (k >> 1)) == 0) {
+          const float a = w[i], b = w[i ^ (k - 1)];
+          w[i] = fminf(a, b);
+          w[i ^ (k - 1)] = fmaxf(a, b);
+        }
+      }
+    } else {
+      constexpr int lm = k / NPL - 1;                        // lane mask; the partner's registers are in reverse order
+      const float sel = (lane & ((lm + 1) >> 1)) == 0 ? -INFINITY : INFINITY;
+      float p[NPL];
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) p[i] = shuffle(w[NPL - 1 - i], std::integral_constant<int, lm>{});
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) w[i] = __builtin_amdgcn_fmed3f(w[i], p[i], sel);
+    }
+    // --- e <-> e ^ j, j = k / 4 ... 1
+    static_for<1, decltype(kc)::value>([&](auto jc) {
       constexpr int j = k >> (decltype(jc)::value + 1);
       if constexpr (j < NPL) {
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
           if ((i & j) == 0) {
-            // direction: bit k of the element index lane * NPL + i
-            const bool up = k < NPL ? ((i & k) == 0) : (((lane * NPL) & k) == 0);
             const float a = w[i], b = w[i | j];
-            const float lo = fminf(a, b), hi = fmaxf(a, b);
-            w[i] = up ? lo : hi;
-            w[i | j] = up ? hi : lo;
+            w[i] = fminf(a, b);
+            w[i | j] = fmaxf(a, b);
           }
         }
       } else {
         constexpr int d = j / NPL;
-        const bool take_min = ((lane & d) == 0) == (((lane * NPL) & k) == 0);     // lower element of an ascending pair, or upper of a descending one
+        const float sel = (lane & d) == 0 ? -INFINITY : INFINITY;
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) {
-          const float p = xor_lane(w[i], std::integral_constant<int, d>{});
-          w[i] = take_min ? fminf(w[i], p) : fmaxf(w[i], p);
-        }
+        for (int i = 0; i < NPL; ++i) w[i] = __builtin_amdgcn_fmed3f(w[i], shuffle(w[i], std::integral_constant<int, d>{}), sel);
       }
     });
   });
