@@ -398,8 +398,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        from speech_decoding_amd.distributed import shutdown
+        lossf.drain()                # the speech rows gathered one batch ahead that no step will consume
+        shutdown()
 
 
 if __name__ == "__main__":

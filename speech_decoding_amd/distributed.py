@@ -52,6 +52,26 @@ def side_group(name: str, group=None):
     return g
 
 
+def shutdown():
+    """Orderly end of a data-parallel run: everything queued on this rank's device is finished, every rank has arrived, the
+    side communicators ("gather", "grads") go first, the default group last.  (Call CLIPLoss.drain() before it when a
+    prefetch may be pending.)  Without the order a rank that leaves early takes its transport threads down under a peer's
+    collective — an abort at exit that looks like a failed run."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    dist.barrier()
+    for g in list(_side_groups.values()):
+        try:
+            dist.destroy_process_group(g)
+        except (ValueError, RuntimeError, AssertionError):
+            pass                     # already gone (or the default group itself at world size 1)
+    _side_groups.clear()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _flat_views(params: Iterable[torch.nn.Parameter]) -> List[torch.Tensor]:
     out = []
     for p in params:

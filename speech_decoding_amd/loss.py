@@ -33,9 +33,23 @@ class LossState:
         self.prefetched = []      # at most one pending prefetch
         self.ring_depth = 2
 
-    def clear(self):
-        self.rings.clear()
+    def drain(self):
+        """Wait for a pending prefetch's collectives (the speech-row all-gather issued one batch ahead and never consumed:
+        the last one of a run) and drop it.  A process group torn down while such a collective is still in flight aborts
+        the process ("terminate called without an active exception": a transport thread destroyed while joinable)."""
+        for item in self.prefetched:
+            works, done = item[7], item[8]
+            if done is not None:
+                done.synchronize()
+            for work in works:
+                work.wait()
+        if self.prefetched and torch.cuda.is_available():
+            torch.cuda.synchronize()
         self.prefetched.clear()
+
+    def clear(self):
+        self.drain()
+        self.rings.clear()
 
 
 _DEFAULT_STATE = LossState()      # for the module-level helpers called without a CLIPLoss instance
@@ -266,6 +280,10 @@ class CLIPLoss(nn.Module):
     def prefetch(self, x: torch.Tensor, compute_dtype=torch.float32):
         """Optional: call with the speech embeddings BEFORE running the encoder (see prefetch_speech)."""
         prefetch_speech(x, compute_dtype, self.global_negatives, state=self._state)
+
+    def drain(self):
+        """Wait for (and drop) a prefetch that no forward will consume — call before tearing the process group down."""
+        self._state.drain()
 
     def release_buffers(self):
         """Drop the persistent packed-speech buffers (e.g. between a training and an evaluation phase)."""

@@ -81,7 +81,8 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
     device = torch.device("cuda", local)
     from speech_decoding_amd.streams import use_training_stream
     use_training_stream(device)          # the loop's chain on a high-priority stream; the engine's side streams stay normal
-    if world > 1 and not dist.is_initialized():
+    owns_group = world > 1 and not dist.is_initialized()
+    if owns_group:
         dist.init_process_group(os.environ.get("SDA_DIST_BACKEND", "nccl"))
     if args.get("reproducible", False):
         np.random.seed(0)
@@ -232,6 +233,10 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
             if wandb is not None:
                 wandb.log(row)
             torch.save(brain_encoder.state_dict(), "model_last.pt")
+    if owns_group:                       # a group this function created is also ended here, in order (distributed.shutdown)
+        from speech_decoding_amd.distributed import shutdown
+        loss_func.drain()
+        shutdown()
     return history, brain_encoder, loss_func
 
 
