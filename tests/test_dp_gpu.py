@@ -117,7 +117,10 @@ def test_two_ranks_on_rccl_when_two_gpus_are_visible():
 def _run_ranks(world, dims, backend):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 29700 + (os.getpid() % 1000) + world + (dims["C"] % 7) * 10
+    import socket
+    with socket.socket() as sock:          # a port the kernel says is free right now (not one derived from the pid)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, world, port, ret, dims, backend)) for r in range(world)]
     for p in procs:
         p.start()
