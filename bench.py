@@ -8,6 +8,10 @@ on one synthetic Gwilliams2022-shaped batch (208 sensors x 360 samples, 27 subje
 256 segments per GPU; BASELINE.json configs[1] at N = 1, configs[2] at N = 8) that is already resident
 in HBM.  Weak scaling: the per-GPU batch is fixed, negatives span the global batch.
 
+`--config 4 | 5` runs the per-GPU shape of BASELINE configs[3] / configs[4] instead (60 ch x 360, 1 subject, 512 / GPU; 306 ch x
+1000, 100 subjects, 512 / GPU, fp16); `--emulate-world 8` runs configs[2]'s PER-RANK step on the one GPU (2048 speech rows, 1792
+of them resident stand-ins for the all-gather's delivery; every collective issued through RCCL at world size 1).
+
 `python bench.py --gpus N` with N > 1 starts its own ranks: a CHILD `python -m torch.distributed.run
 --nproc-per-node N bench.py ...` is spawned before this process touches the GPU, and its exit code is returned.
 Under `torch.distributed.run` (RANK/WORLD_SIZE set) it runs as one rank.
@@ -31,6 +35,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 C, S, T, F, D1, D2, K = 208, 27, 360, 1024, 270, 320, 32
+# per-GPU shapes of the BASELINE.json configs that run on one MI355X (`--config N`, circled numbers of SURVEY.md §8d):
+#   2 = configs[1] (the headline), 4 = configs[3] per rank (60 ch, 1 subject, 512 / GPU), 5 = configs[4] per rank
+#   (306 ch x 1000 samples, 100 subjects, 512 / GPU, fp16); configs[2] per rank = config 2 with --emulate-world 8
+CONFIGS = {2: dict(C=208, S=27, T=360, batch=256, dtype="bf16", name="configs[1]"),
+           4: dict(C=60, S=1, T=360, batch=512, dtype="bf16", name="configs[3] per-rank shape (60 ch, batch 4096 global = 512 x 8)"),
+           5: dict(C=306, S=100, T=1000, batch=512, dtype="fp16", name="configs[4] per-rank shape (306 ch x 5 s @200 Hz, batch 4096 global = 512 x 8)")}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 
 
@@ -39,8 +49,15 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
-    ap.add_argument("--batch", type=int, default=256, help="segments per GPU")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"], help="default: the config's (bf16; fp16 for config 5)")
+    ap.add_argument("--batch", type=int, default=None, help="segments per GPU (default: the config's, 256 / 512 / 512)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE config whose per-GPU shape is run")
+    ap.add_argument("--emulate-world", type=int, default=1, help="N = 1 only: run the per-rank step of an N-rank job — N x batch "
+                    "speech rows ((N - 1) x batch of them resident stand-ins for what the all-gather would have delivered), "
+                    "every collective issued for real through RCCL at world size 1.  A compute-side bound, not a scaling curve")
+    ap.add_argument("--emulate-no-copy", action="store_true", help="--emulate-world: leave the stand-in rows in place instead of "
+                    "re-delivering them (a 1.3 GB device copy beside the forward) every step")
+    ap.add_argument("--no-feed-leg", action="store_true", help="skip the extra loop fed by ResidentSegmentFeed + ShardedRandomSampler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-steps", type=int, default=3, help="instrumented steps run after the timed region")
@@ -177,9 +194,22 @@ def pmc_traffic(dtype: str, tile_co: int, ks: int, kind: str = "conv_gemm"):
 
 
 def main():
+    global C, S, T
     a = parse_args()
+    shape = CONFIGS[a.config]
+    C, S, T = shape["C"], shape["S"], shape["T"]
+    a.batch = a.batch or shape["batch"]
+    a.dtype = a.dtype or shape["dtype"]
+    if a.emulate_world > 1 and a.gpus > 1:
+        sys.exit("bench.py: --emulate-world is a one-GPU measurement (use --gpus N on a node that has N)")
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(a))
+
+    # ONE JSON line on stdout, whatever the libraries below choose to print there (RCCL's version banner goes to stdout):
+    # everything written to file descriptor 1 from here on lands on stderr, the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -195,12 +225,27 @@ def main():
     if not os.environ.get("SDA_DEFAULT_STREAM"):      # (diagnostic: SDA_DEFAULT_STREAM=1 keeps torch's default stream)
         from speech_decoding_amd.streams import use_training_stream
         use_training_stream(dev)                      # the step's chain on a high-priority stream (side streams stay normal)
+    emu = a.emulate_world if world == 1 else 1
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    elif emu > 1:
+        # one rank, data-parallel code path ON: every collective of the step goes through the backend (RCCL) at world size 1
+        os.environ["SDA_DP_SINGLE_RANK"] = "1"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        kw = dict(device_id=dev) if backend == "nccl" else {}
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
+        from speech_decoding_amd import distributed as sda_dist
+        from speech_decoding_amd import loss as _l
+        sda_dist.emulate_world(emu)
+        _l.EMULATE_COPY_REMOTE = not a.emulate_no_copy
+    dp = world > 1 or emu > 1
 
     from speech_decoding_amd import BrainEncoder, CLIPLoss, load_config, ops
     from speech_decoding_amd.layout import synthetic_positions
@@ -222,7 +267,7 @@ def main():
     from speech_decoding_amd.optim import FusedAdam        # same rule as torch.optim.Adam, one launch
     opt = FusedAdam(params, lr=float(cfg.lr))
     from speech_decoding_amd.amp import LossScaler
-    scaler = LossScaler.for_dtype(enc.compute_dtype, global_batch=a.batch * world, T=T)   # static loss scale for fp16 (grows with
+    scaler = LossScaler.for_dtype(enc.compute_dtype, global_batch=a.batch * world * emu, T=T)   # static loss scale for fp16 (grows with
                                                                                            # the global batch); a no-op for bf16 / fp32
 
     # synthetic data pool resident in HBM: X ~ N(0,1) clamped ±20; Y = P·X + 0.5·eps (learnable structure).
@@ -248,20 +293,25 @@ def main():
     # Under data parallelism the speech rows of the NEXT batch are packed and all-gathered (197 MB per rank and step at
     # config 3) while THIS step's backward runs, like a data loader that is one batch ahead: five milliseconds of cover
     # instead of the forward's two and a half.  The loss keeps two packed buffers in rotation for exactly this overlap.
-    ahead = world > 1 and not a.no_prefetch_ahead
+    ahead = dp and not a.no_prefetch_ahead
     primed = [False]
 
-    def step(i, host_sync=False):
-        X, Y = pool[i % len(pool)]
-        subj = torch.from_numpy(subj_rng.randint(0, S, size=B).astype(np.int32))
-        if not (ahead and primed[0]):
+    def step(i, host_sync=False, batch=None, after_forward=None):
+        if batch is None:
+            X, Y = pool[i % len(pool)]
+            subj = torch.from_numpy(subj_rng.randint(0, S, size=B).astype(np.int32))
+        else:                                                # the feed leg: (X, Y, subject indices) from the input path
+            X, Y, subj = batch
+        if not (ahead and primed[0]) or batch is not None:
             lossf.prefetch(Y, enc.compute_dtype)             # pack Y (+ all-gather it under DP) while the encoder runs
         Z = enc(X, subj)
         loss = lossf(Y, Z)
         cnt = sda_loss.retrieval_ranks(Y, Z)                 # Classifier semantics (train.py:193-194)
-        if ahead:
+        if ahead and batch is None:
             lossf.prefetch(pool[(i + 1) % len(pool)][1], enc.compute_dtype)
             primed[0] = True
+        if after_forward is not None:
+            after_forward()
         if host_sync:                                        # what train.py does every step: loss.item() + top-k on the host
             float(loss.detach())
             cnt = cnt.cpu()
@@ -269,7 +319,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         scaler.scale(loss).backward(gradient=one)            # (a resident d loss / d loss = 1: autograd would fill a fresh one per step)
         scaler.unscale_(params)
-        if world > 1:      # encoder gradients were all-reduced inside backward (overlapped); temp is left
+        if dp:             # encoder gradients were all-reduced inside backward (overlapped); temp is left
             allreduce_gradients(list(lossf.parameters()) if enc.grads_are_reduced else params)
         opt.step()
         return loss
@@ -338,6 +388,68 @@ def main():
         dt_sync /= n_sync
         nxt += n_sync
 
+    # The input path inside a timed loop (gwilliams2022.py:129-142,640-661, get_dataloaders.py:48-87): the
+    # recordings resident in HBM, the reference's RandomSampler(replacement=True) cut into rank shards, and every step's batch
+    # made by ONE kernel (window gather + baseline correction + robust scaling + clamp) plus the speech rows' gather from the
+    # resident embedding table — on a stream of its own, one batch ahead of the step that consumes it, like a data loader.
+    dt_feed = None
+    if a.config == 2 and world == 1 and emu == 1 and not a.no_feed_leg:
+        from speech_decoding_amd.data import ShardedRandomSampler, synthetic_resident_dataset
+        n_feed = max(3, min(20, a.steps))
+        feed, train_idx, _ = synthetic_resident_dataset(cfg, dev, n_segments=4 * B, seed=1234)
+        sampler = ShardedRandomSampler(len(train_idx), B, n_feed + 5, rank, world, seed=4321)
+        # The feed's stream has LOW priority (the step's chain is the critical path: a freed CU slot goes to it first) and starts
+        # batch i + 1 behind step i's loss forward, i.e. beside the backward pass: the forward's k = 3 convs are ONE round of
+        # persistent workgroups sized to the whole chip, and a slot taken from them by another stream's kernel is a straggler.
+        # (SDA_FEED_AT=start / SDA_FEED_PRIO=0: diagnostics — the batch made beside the forward / at normal priority)
+        feed_at = os.environ.get("SDA_FEED_AT", "backward")
+        feed_prio = int(os.environ.get("SDA_FEED_PRIO", "1"))
+        feed_stream = (torch.cuda.ExternalStream(ops.stream_create_priority(feed_prio), device=dev) if feed_prio > 0
+                       else torch.cuda.Stream(device=dev, priority=feed_prio))
+        main_stream = torch.cuda.current_stream(dev)
+        it = iter(sampler)
+
+        def produce(behind_main=False):
+            idx = next(it, None)
+            if idx is None:
+                return None
+            if behind_main:
+                gate = torch.cuda.Event()
+                gate.record(main_stream)
+                feed_stream.wait_event(gate)
+            with torch.cuda.stream(feed_stream):
+                Xf, Yf, sf = feed.batch(train_idx[idx.numpy()])
+                ev = torch.cuda.Event()
+                ev.record(feed_stream)
+            return Xf, Yf, sf, ev
+
+        def feed_step(i, nxt_batch):
+            Xf, Yf, sf, ev = nxt_batch
+            main_stream.wait_event(ev)
+            Xf.record_stream(main_stream)
+            Yf.record_stream(main_stream)
+            box = []
+            if feed_at == "start":
+                box.append(produce())                        # batch i + 1 is made while step i runs, from its start
+                step(i, batch=(Xf, Yf, sf))
+            else:
+                step(i, batch=(Xf, Yf, sf), after_forward=lambda: box.append(produce(behind_main=True)))
+            return box[0]
+
+        primed[0] = False
+        pending = produce()
+        n_warm = 4                                           # untimed: the feed's streams exist, the allocator has its blocks
+        for i in range(n_warm):
+            pending = feed_step(nxt + i, pending)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n_feed):
+            pending = feed_step(nxt + n_warm + i, pending)
+        fence()
+        dt_feed = (time.perf_counter() - t0) / n_feed
+        nxt += n_warm + n_feed
+        del feed, pending
+
     timer = None
     if not a.no_kernel_timer and a.timer_steps > 0:          # roofline leg, outside the timed region
         timer = ops.KernelTimer(("conv_gemm", "wgrad_gemm"))
@@ -349,7 +461,7 @@ def main():
         ops.TIMER = None
 
     coll = None
-    if world > 1 and a.coll_timer_steps > 0:                 # what each collective costs the stream that waits for it
+    if dp and a.coll_timer_steps > 0:                        # what each collective costs the stream that waits for it
         from speech_decoding_amd.distributed import CollectiveTimer
         fence()
         ct = CollectiveTimer().install()
@@ -367,24 +479,36 @@ def main():
             "value": round(B * world * a.steps / dt, 2), "unit": "segments/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"Gwilliams2022-shaped MEG: {C} ch x {T} samples (3 s @120 Hz), {S} subjects, "
-                                   f"F={F}, batch {B}/GPU, fwd+CLIP loss+top-k+bwd+Adam (BASELINE configs[1]"
-                                   f"{' / configs[2]' if world == 8 else ''})",
-                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}"},
+            "config": {"workload": (f"{'Gwilliams2022-shaped MEG' if C != 60 else 'Brennan2018-shaped EEG'}: {C} ch x {T} samples, "
+                                    f"{S} subjects, F={F}, batch {B}/GPU, fwd+CLIP loss+top-k+bwd+Adam (BASELINE {shape['name']}"
+                                    f"{' / configs[2]' if world == 8 and a.config == 2 else ''})"
+                                    + (f"; PER-RANK step of a {emu}-rank job on ONE GPU: {B * emu} speech rows of which {B * (emu - 1)} are "
+                                       f"resident stand-ins for the all-gather's delivery"
+                                       f"{' (re-delivered by a device copy every step)' if not a.emulate_no_copy else ''}, logits block "
+                                       f"{B * emu} x {B}, SyncBN all-reduces / loss-statistics gather / gradient buckets issued through "
+                                       f"RCCL at world size 1 (BASELINE configs[2] per-rank step when N = 8: a compute-side bound, not a scaling curve)"
+                                       if emu > 1 else "")),
+                       "global_batch": B * world * emu, "seq_len": T, "parallelism": f"dp{world}" + (f" (emulating dp{emu})" if emu > 1 else "")},
             "top10_acc": round(top10, 4), "top1_acc": round(top1, 4),
-            "top10_note": f"held-out batch of {B * world} segments never trained on (eval mode, chance = {10.0 / (B * world):.4f}); "
+            "top10_note": f"held-out batch of {B * world} segments never trained on (eval mode, chance = {10.0 / (B * world * emu):.4f}); "
                           f"on the last three TRAINING batches: {top10_train:.4f}",
             "final_loss": round(final_loss, 4),
         }
         if dt_sync is not None:
             out["host_synced"] = {"value": round(B * world / dt_sync, 2), "ms_per_step": round(1e3 * dt_sync, 3),
                                   "note": "same step with loss.item() and the ranks read back on the host every step (train.py:194-196)"}
+        if dt_feed is not None:
+            out["with_feed"] = {"value": round(B * world / dt_feed, 2), "ms_per_step": round(1e3 * dt_feed, 3),
+                                "note": "same step fed by ResidentSegmentFeed + ShardedRandomSampler every step: window gather + baseline "
+                                        "correction + robust scaling + clamp (one kernel) and the speech rows' gather, on a stream of "
+                                        "their own one batch ahead (gwilliams2022.py:129-142,640-661; get_dataloaders.py:48-87)"}
         if timer is not None:
             summ = timer.summary()
             key = max(summ, key=lambda k: summ[k][2])             # dominant = most total time
             n, flops, ms = summ[key]
             ach = flops / (ms * 1e-3) / 1e12
-            traffic, src = pmc_traffic(a.dtype, key[2], key[3], key[0])
+            # (the committed PMC passes are of the headline configuration only)
+            traffic, src = pmc_traffic(a.dtype, key[2], key[3], key[0]) if (a.config == 2 and emu == 1 and B == 256) else (None, None)
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic, "traffic_source": src,
                                "kernel": f"{key[0]}<{key[1]},TILE={key[2]},KS={key[3]}>", "launches": n,
@@ -394,10 +518,11 @@ def main():
             out["kernel_tflops"] = {f"{k[0]}<{k[1]},{k[2]},{k[3]}>": round(v[1] / (v[2] * 1e-3) / 1e12, 1) for k, v in summ.items() if v[2] > 0}
         if coll is not None:
             out["collectives_us_per_step"] = coll
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and emu == 1 and a.config == 2 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dp:
         from speech_decoding_amd.distributed import shutdown
         lossf.drain()                # the speech rows gathered one batch ahead that no step will consume
         shutdown()

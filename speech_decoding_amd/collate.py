@@ -62,8 +62,11 @@ class ResidentSegments:
         if bool(((on < 0) | (on + self.T > self._len[sidx])).any()):
             raise IndexError("segment window leaves its session recording")
         dev = self.sessions[0].device
-        ptrs = (self._base[sidx] + 4 * on).to(dev, non_blocking=True)
-        cstr = self._len[sidx].to(dev, non_blocking=True)
+        # the two index tables travel in kernel arguments (ops.upload_small): a copy from pageable host memory makes the host
+        # wait for the stream it is queued on — with the step's loop two milliseconds ahead of the GPU that wait is the step's
+        with torch.cuda.device(dev):
+            ptrs = ops.upload_small((self._base[sidx] + 4 * on).numpy(), dev)
+            cstr = ops.upload_small(self._len[sidx].numpy(), dev)
         out = torch.empty((len(sidx), self.C, self.T), dtype=torch.float32, device=dev)
         L.check(L.load().sda_collate_windows(ptrs.data_ptr(), cstr.data_ptr(), out.data_ptr(), len(sidx), self.C, self.T, self.nb,
                                              self.lim, int(self.clamp), torch.cuda.current_stream().cuda_stream), "collate_windows")

@@ -69,23 +69,65 @@ class ResidentSegmentFeed:
         # (gwilliams2022.py:133 draws the recording from NumPy's GLOBAL generator inside DataLoader workers; the global
         # generator stays reserved for SpatialDropout's centre here — every rank must draw that one in lockstep)
         self.rng = np.random.RandomState(seed)
+        # dense tables for the vectorised draw / onset lookup (None where the structure is ragged: the loops remain)
+        self._task_keys = np.array(sorted(self.by_task), dtype=self.rec_task.dtype)
+        counts = {len(v) for v in self.by_task.values()}
+        self._rec_table = np.stack([self.by_task[int(t)] for t in self._task_keys]) if len(counts) == 1 else None
+        lens = {len(o) for o in self.onsets}
+        self._onset_table = np.stack(self.onsets) if len(lens) == 1 else None
 
     def __len__(self) -> int:
         return int(self.Y.shape[0])
 
-    def batch(self, idx) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def draw_recordings(self, idx) -> np.ndarray:
+        """gwilliams2022.py:133: one random recording of each segment's task, drawn item by item from the feed's generator
+        (`rng.choice(recordings of the task)`).  When every task has the same number of recordings the whole batch is ONE
+        vectorised draw — the same stream of values as the item-by-item calls (checked in tests/test_host_cpu.py), without
+        256 Python-level generator calls in front of a 7 ms step."""
+        ii = np.asarray(idx, dtype=np.int64)
+        tasks = self.seg_task[ii]
+        if self._rec_table is not None:
+            u = self.rng.randint(0, self._rec_table.shape[1], size=len(ii))
+            return self._rec_table[np.searchsorted(self._task_keys, tasks), u].astype(np.int64)
+        return np.array([self.rng.choice(self.by_task[int(t)]) for t in tasks], dtype=np.int64)
+
+    def batch(self, idx, rec=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """idx: this rank's global segment indices; rec: their recordings when the caller drew them (data parallelism: the
+        draws are made for the GLOBAL batch on every rank alike and sliced, see batches())."""
         idx = torch.as_tensor(idx, dtype=torch.int64)
         ii = idx.numpy()
-        tasks = self.seg_task[ii]
-        rec = np.array([self.rng.choice(self.by_task[int(t)]) for t in tasks], dtype=np.int64)
-        on = np.array([self.onsets[r][j] for r, j in zip(rec, self.seg_in_task[ii])], dtype=np.int64)
+        rec = self.draw_recordings(ii) if rec is None else np.asarray(rec, dtype=np.int64)
+        on = self._onset_of(rec, self.seg_in_task[ii])
         X = self.rs.batch(rec, on)
-        Y = self.Y.index_select(0, idx.to(self.Y.device))
+        if self.Y.is_cuda:
+            from . import ops
+            with torch.cuda.device(self.Y.device):
+                Y = self.Y.index_select(0, ops.upload_small(ii, self.Y.device))    # (index table in kernel arguments: no host wait)
+        else:
+            Y = self.Y.index_select(0, idx)
         return X, Y, torch.from_numpy(self.rec_subject[rec].astype(np.int32))
 
-    def batches(self, sampler) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+    def _onset_of(self, rec: np.ndarray, j: np.ndarray) -> np.ndarray:
+        if self._onset_table is not None:
+            return self._onset_table[rec, j]
+        return np.array([self.onsets[r][k] for r, k in zip(rec, j)], dtype=np.int64)
+
+    def batches(self, sampler, index_map=None) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """One (X, Y, subject_idxs) per batch of `sampler`.  With a ShardedRandomSampler the recording of EVERY segment of the
+        global batch is drawn on every rank from the same generator state and the rank keeps its slice — the union over the
+        ranks is exactly the batch a single process would have drawn, and no two ranks share a draw.  `index_map`: optional
+        array mapping sampler indices to segment indices (a train split)."""
+        if hasattr(sampler, "global_batches") and getattr(sampler, "world", 1) > 1:
+            per = sampler.batch_size // sampler.world
+            lo = sampler.rank * per
+            for gidx in sampler.global_batches():
+                g = gidx.numpy() if index_map is None else np.asarray(index_map)[gidx.numpy()]
+                rec = self.draw_recordings(g)
+                yield self.batch(g[lo: lo + per], rec=rec[lo: lo + per])
+            return
         for idx in sampler:
-            yield self.batch(idx)
+            i = idx.numpy() if isinstance(idx, torch.Tensor) else np.asarray(idx)
+            yield self.batch(i if index_map is None else np.asarray(index_map)[i])
 
 
 def synthetic_resident_dataset(args, device, *, n_segments: int, n_tasks: int = 4, seed: int = 1234) -> Tuple[ResidentSegmentFeed, np.ndarray, np.ndarray]:

@@ -33,6 +33,25 @@ def active_group():
     return None
 
 
+_EMULATED_WORLD = 1
+
+
+def emulate_world(n: int):
+    """Measurement aid (bench.py --emulate-world N): with ONE rank (SDA_DP_SINGLE_RANK=1) the loss behaves as rank 0 of an
+    N-rank job — its speech-row buffer holds N * B_local samples of which (N - 1) * B_local are resident stand-ins for the rows
+    the all-gather would have delivered, the logits block is (N * B_local) x B_local, the loss is normalised by the global
+    batch — while every collective of the step is issued for real at world size 1.  What it measures is the COMPUTE side of a
+    rank's step at the N-rank shape; the wire is not in it."""
+    global _EMULATED_WORLD
+    if n < 1:
+        raise ValueError("emulate_world: n >= 1")
+    _EMULATED_WORLD = int(n)
+
+
+def emulated_world() -> int:
+    return _EMULATED_WORLD
+
+
 def side_group(name: str, group=None):
     """A second communicator over the same ranks as `group` (default: WORLD), created once per name.
 
@@ -97,7 +116,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
         nonlocal bucket, size
         if not bucket:
             return
-        if len(bucket) == 1:
+        if len(bucket) == 1 and bucket[0].grad.is_contiguous():
             g = bucket[0].grad
             dist.all_reduce(torch.view_as_real(g) if g.is_complex() else g, op=dist.ReduceOp.SUM, group=group)
         else:

@@ -665,6 +665,13 @@ class EncoderEngine:
                 W0cat = self._const[key] = torch.zeros((d.D1, 3, d.D2p), dtype=torch.float32, device=dev)
             _w0 = W0cat
             on_side(lambda: ops.copy3d(_w0[:, :, : d.D2], P["b0.c0w"].permute(1, 2, 0)))
+            # its reader (the G product at the end of backward) runs on the MAIN stream: an event of the side stream right
+            # behind the copy, waited for just before that product (long complete by then: the wait costs nothing, and the
+            # result no longer depends on how far the side stream has got)
+            w0cat_ready = None
+            if side is not None:
+                w0cat_ready = torch.cuda.Event()
+                w0cat_ready.record(side)
 
         def dgrad(dy, key, w_fp32, Cout_p, Cin_p, out, KS, dil, res=None, widx=None, bn=None, glu_bwd=None, **glu):
             """Data-gradient conv.  bn = (h, coef): `out` is the gradient entering GELU(BN(h)); the conv's epilogue
@@ -825,6 +832,8 @@ class EncoderEngine:
                                    seg_start=ctx.subj_seg, nseg=r * d.S)     # (r*S, 3, D2p, Cp); column C: the folded bias
                 if r > 1:
                     M = ops.reduce_slabs(M.view(r, -1))
+                if w0cat_ready is not None:
+                    self._wait("W0cat copy (side stream)", main, w0cat_ready)
                 G = ops.param_gemm(W0cat.view(d.D1, 3 * d.D2p), M.view(d.S, 3 * d.D2p, d.Cp)[:, :, : d.C + 1])   # (S, D1, C + 1)
             else:
                 slabs = ops.wgrad_gemm(dhs, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg,

@@ -32,6 +32,7 @@ class LossState:
         self.rings = {}           # (key, B, C, T, dtype, device) -> [buffers, next index, generations]
         self.prefetched = []      # at most one pending prefetch
         self.ring_depth = 2
+        self.emulated = {}        # distributed.emulate_world: the resident stand-ins for the other ranks' speech rows
 
     def drain(self):
         """Wait for a pending prefetch's collectives (the speech-row all-gather issued one batch ahead and never consumed:
@@ -50,6 +51,7 @@ class LossState:
     def clear(self):
         self.drain()
         self.rings.clear()
+        self.emulated.clear()
 
 
 _DEFAULT_STATE = LossState()      # for the module-level helpers called without a CLIPLoss instance
@@ -151,6 +153,9 @@ def gather_speech_rows(Yt_local: torch.Tensor, B: int, T: int, group, async_op: 
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     Tp = L.rows_tp(T)
+    from .distributed import emulated_world
+    if world == 1 and emulated_world() > 1:
+        return _gather_emulated(Yt_local, ysq_local, B, T, group, emulated_world(), async_op, state or _DEFAULT_STATE)
     slot = _ring_rows(state or _DEFAULT_STATE, "loss.Yall", B * world, Yt_local.shape[1], T, Yt_local.dtype, Yt_local.device)
     Yt = slot.buf
     ysq = torch.empty(B * world, dtype=torch.float32, device=Yt_local.device)
@@ -159,6 +164,41 @@ def gather_speech_rows(Yt_local: torch.Tensor, B: int, T: int, group, async_op: 
     w1 = dist.all_gather_into_tensor(Yt[: B * world * Tp], Yt_local[: B * Tp], group=bulk, async_op=async_op)
     w2 = dist.all_gather_into_tensor(ysq, ysq_local, group=bulk, async_op=async_op)
     return Yt, ysq, B * world, rank * B, B * world, ([w1, w2] if async_op else []), slot
+
+
+EMULATE_COPY_REMOTE = True      # emulated world: re-deliver the stand-in rows every step (a device copy in place of the wire)
+
+
+def _gather_emulated(Yt_local, ysq_local, B, T, group, W, async_op, state: LossState):
+    """distributed.emulate_world(W) at world size 1: this rank is rank 0 of W.  Its own rows travel through the real
+    all-gather (one rank); the (W - 1) * B rows of the other ranks are resident stand-ins (seeded N(0, 1) rows packed by
+    sda_pack_rows, norms by sda_rows_sumsq), copied into the gathered buffer every step on the stream the gather is issued
+    from — HBM sees the bytes a real gather would have landed (plus the copy's reads)."""
+    import torch.distributed as dist
+    from .distributed import side_group
+    Tp, Cp, dev, dt = L.rows_tp(T), Yt_local.shape[1], Yt_local.device, Yt_local.dtype
+    key = ("remote", B, W, Cp, T, dt, str(dev))
+    rem = state.emulated.get(key)
+    if rem is None:
+        rows = torch.zeros(((W - 1) * B * Tp, Cp), dtype=dt, device=dev)
+        nsq = torch.empty((W - 1) * B, dtype=torch.float32, device=dev)
+        g = torch.Generator(device=dev).manual_seed(4242)
+        tmp = ops.new_rows(B, T, Cp, dt, dev)
+        for k in range(W - 1):
+            ops.pack_rows(torch.randn((B, Cp, T), generator=g, device=dev), tmp)
+            rows[k * B * Tp: (k + 1) * B * Tp].copy_(tmp[: B * Tp])
+            nsq[k * B: (k + 1) * B] = ops.rows_sumsq(tmp, B, Tp * Cp, Tp * Cp)
+        rem = state.emulated[key] = (rows, nsq)
+    slot = _ring_rows(state, "loss.Yall", B * W, Cp, T, dt, dev)
+    Yt = slot.buf
+    ysq = torch.empty(B * W, dtype=torch.float32, device=dev)
+    bulk = side_group("gather", group)
+    w1 = dist.all_gather_into_tensor(Yt[: B * Tp], Yt_local[: B * Tp], group=bulk, async_op=async_op)
+    w2 = dist.all_gather_into_tensor(ysq[:B], ysq_local, group=bulk, async_op=async_op)
+    if EMULATE_COPY_REMOTE or slot.gen == 1:
+        Yt[B * Tp: W * B * Tp].copy_(rem[0])
+    ysq[B:].copy_(rem[1])
+    return Yt, ysq, B * W, 0, B * W, ([w1, w2] if async_op else []), slot
 
 
 _prefetch_streams = {}    # device -> side stream the speech-side work runs on

@@ -254,3 +254,54 @@ def test_sharded_random_sampler_is_the_global_sampler_cut_into_rank_slices():
     import pytest
     with pytest.raises(ValueError):
         ShardedRandomSampler(10, 9, 1, 0, 2)
+
+
+def _toy_feed(monkeypatch, seed=5):
+    """ResidentSegmentFeed with the device kernel replaced by a recorder (host logic only)."""
+    from speech_decoding_amd import data as D
+
+    class FakeSegments:
+        def __init__(self, sessions, *a, **k):
+            self.sessions = sessions
+            self.calls = []
+
+        def batch(self, rec, on):
+            self.calls.append((np.asarray(rec).copy(), np.asarray(on).copy()))
+            return torch.zeros(len(rec), 2, 3)
+    monkeypatch.setattr(D, "ResidentSegments", FakeSegments)
+    n_task, per = 4, 10
+    onsets = [np.arange(per, dtype=np.int64) * 5 + 7 * (r % 2) for r in range(2 * n_task)]
+    return D.ResidentSegmentFeed([None] * (2 * n_task), list(range(2 * n_task)), np.repeat(np.arange(n_task), 2), onsets,
+                                 np.repeat(np.arange(n_task), per), np.tile(np.arange(per), n_task), torch.zeros(n_task * per, 2, 3),
+                                 seq_len_samp=3, baseline_len_samp=1, clamp_lim=20.0, seed=seed)
+
+
+def test_feed_vectorised_draw_equals_item_by_item_choice(monkeypatch):
+    """gwilliams2022.py:133 draws one recording per item; the feed draws a batch at once — the same stream of values."""
+    feed = _toy_feed(monkeypatch, seed=5)
+    twin = np.random.RandomState(5)
+    for idx in (np.array([3, 17, 17, 39, 0, 21]), np.arange(40)):
+        rec = feed.draw_recordings(idx)
+        want = [int(twin.choice(feed.by_task[int(feed.seg_task[i])])) for i in idx]
+        assert rec.tolist() == want
+        on = feed._onset_of(rec, feed.seg_in_task[idx])
+        assert on.tolist() == [int(feed.onsets[r][feed.seg_in_task[i]]) for r, i in zip(rec, idx)]
+
+
+def test_feed_rank_shards_union_to_the_single_process_batch(monkeypatch):
+    """Data parallelism: every rank draws the recordings of the GLOBAL batch from the same generator state and keeps its slice —
+    the union over ranks is the batch one process would have made, and no two ranks share a draw."""
+    from speech_decoding_amd.data import ShardedRandomSampler
+    single = _toy_feed(monkeypatch, seed=9)
+    s1 = ShardedRandomSampler(40, 8, 5, rank=0, world=1, seed=3)
+    list(single.batches(s1))
+    ref = single.rs.calls
+    parts = []
+    for rank in range(2):
+        f = _toy_feed(monkeypatch, seed=9)
+        list(f.batches(ShardedRandomSampler(40, 8, 5, rank=rank, world=2, seed=3)))
+        parts.append(f.rs.calls)
+    for b in range(5):
+        rec = np.concatenate([parts[0][b][0], parts[1][b][0]])
+        on = np.concatenate([parts[0][b][1], parts[1][b][1]])
+        assert rec.tolist() == ref[b][0].tolist() and on.tolist() == ref[b][1].tolist()

@@ -95,5 +95,69 @@ def early_touch(lines):
     return bad
 
 
+def audit_disassembly(path, quiet=False):
+    """The same two properties on `llvm-objdump -d` output of a BUILT gfx950 code object (what actually ships; wired into
+    tests/test_asm_audit_cpu.py next to the register-spill guard):
+      * no global_load_lds whose scalar base pair was written by a VALU instruction inside the 5 wait states before it;
+      * M0 belongs to the LDS-DMA statements alone: the asm statements write it and do not save it, which is only sound while
+        hipcc keeps no value of its own there — every instruction that names m0 must be an `s_mov_b32 m0, <scalar>` whose next
+        instruction but s_nop is a global_load_lds (the statement's own pattern); anything else (a read of m0, an LDS / GWS /
+        movrel / sendmsg use, a write that feeds something else) is reported.
+    Returns (hazards, m0_violations, lds_dma_count)."""
+    hazards = m0_bad = ndma = 0
+    kernel, hist = "", []
+    pending_m0 = None                                     # text of an `s_mov_b32 m0` still waiting for its global_load_lds
+    for ln in open(path):
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+        if m:
+            if pending_m0:
+                m0_bad += 1
+                if not quiet: print(f"M0 in {kernel[:80]}: '{pending_m0}' is not followed by an LDS-DMA")
+            kernel, hist, pending_m0 = m.group(1), [], None
+            continue
+        if not ln.startswith("\t"):
+            continue
+        t = ln.split("//")[0].strip()
+        if not t:
+            continue
+        op = t.split()[0]
+        is_dma = op.startswith("global_load_lds")
+        if is_dma:
+            ndma += 1
+            mm = re.search(r"s\[(\d+):(\d+)\]", t)
+            if mm:
+                regs = {f"s{mm.group(1)}", f"s{mm.group(2)}"}
+                wait = 0
+                for prev in reversed(hist[-8:]):
+                    pop = prev.split()[0]
+                    if pop == "s_nop":
+                        wait += int(prev.split()[1], 0) + 1
+                        continue
+                    dst = prev.split()[1].rstrip(",") if len(prev.split()) > 1 else ""
+                    if pop.startswith("v_") and dst in regs and wait < 5:
+                        hazards += 1
+                        if not quiet: print(f"HAZARD in {kernel[:80]}: '{prev}' feeds '{t}' after {wait} wait states")
+                    wait += 1
+                    if wait >= 5:
+                        break
+            pending_m0 = None
+        elif pending_m0 is not None and op != "s_nop":
+            m0_bad += 1
+            if not quiet: print(f"M0 in {kernel[:80]}: '{pending_m0}' is followed by '{t}', not by an LDS-DMA")
+            pending_m0 = None
+        if re.search(r"\bm0\b", t) and not is_dma:
+            if re.match(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi|ttmp\d+|0x[0-9a-f]+|\d+)$", t):
+                pending_m0 = t
+            else:
+                m0_bad += 1
+                if not quiet: print(f"M0 in {kernel[:80]}: '{t}' uses M0 outside an LDS-DMA statement")
+        hist.append(t)
+    return hazards, m0_bad, ndma
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--dis":
+        h, m, n = audit_disassembly(sys.argv[2])
+        print(f"{sys.argv[2]}: {n} LDS-DMA instructions, {h} scalar-base hazards, {m} foreign uses of M0")
+        sys.exit(1 if (h or m) else 0)
     sys.exit(1 if main(*sys.argv[1:]) else 0)

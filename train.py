@@ -80,6 +80,7 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     from speech_decoding_amd.streams import use_training_stream
+    caller_stream = torch.cuda.current_stream(device)
     use_training_stream(device)          # the loop's chain on a high-priority stream; the engine's side streams stay normal
     owns_group = world > 1 and not dist.is_initialized()
     if owns_group:
@@ -107,8 +108,8 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
         def train_batches():
             sampler = ShardedRandomSampler(len(train_idx), int(args.batch_size), updates, rank, world, seed=4321 + epoch_no[0])
             epoch_no[0] += 1
-            for idx in sampler:
-                yield feed.batch(train_idx[idx.numpy()])
+            # (under data parallelism the recordings of the whole global batch are drawn on every rank alike and sliced)
+            yield from feed.batches(sampler, index_map=train_idx)
 
         def test_batch():
             lo, hi = shard_range(len(test_idx), rank, world)
@@ -237,6 +238,9 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
         from speech_decoding_amd.distributed import shutdown
         loss_func.drain()
         shutdown()
+    # hand the thread back on the stream it came with (everything queued on the training stream is waited for first)
+    caller_stream.wait_stream(torch.cuda.current_stream(device))
+    torch.cuda.set_stream(caller_stream)
     return history, brain_encoder, loss_func
 
 
