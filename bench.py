@@ -397,6 +397,7 @@ def main():
         from speech_decoding_amd.data import ShardedRandomSampler, synthetic_resident_dataset
         n_feed = max(3, min(20, a.steps))
         feed, train_idx, _ = synthetic_resident_dataset(cfg, dev, n_segments=4 * B, seed=1234)
+        feed.pack_embeddings(enc.compute_dtype)              # the embedding table resident in row layout: Y arrives packed
         sampler = ShardedRandomSampler(len(train_idx), B, n_feed + 5, rank, world, seed=4321)
         # The feed's stream has LOW priority (the step's chain is the critical path: a freed CU slot goes to it first) and starts
         # batch i + 1 behind step i's loss forward, i.e. beside the backward pass: the forward's k = 3 convs are ONE round of
@@ -423,8 +424,15 @@ def main():
                 ev.record(feed_stream)
             return Xf, Yf, sf, ev
 
+        feed_dbg = os.environ.get("SDA_FEED_DEBUG", "")    # "discard": make every batch but train on the pool (diagnostic)
+
         def feed_step(i, nxt_batch):
             Xf, Yf, sf, ev = nxt_batch
+            if feed_dbg == "discard":
+                main_stream.wait_event(ev)
+                nb = produce()
+                step(i)
+                return nb
             main_stream.wait_event(ev)
             Xf.record_stream(main_stream)
             Yf.record_stream(main_stream)
@@ -445,6 +453,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(n_feed):
             pending = feed_step(nxt + n_warm + i, pending)
+        host_feed = (time.perf_counter() - t0) / n_feed      # the host's enqueue time per step (it runs ahead of the GPU)
         fence()
         dt_feed = (time.perf_counter() - t0) / n_feed
         nxt += n_warm + n_feed
@@ -499,6 +508,7 @@ def main():
                                   "note": "same step with loss.item() and the ranks read back on the host every step (train.py:194-196)"}
         if dt_feed is not None:
             out["with_feed"] = {"value": round(B * world / dt_feed, 2), "ms_per_step": round(1e3 * dt_feed, 3),
+                                "host_enqueue_ms_per_step": round(1e3 * host_feed, 3),
                                 "note": "same step fed by ResidentSegmentFeed + ShardedRandomSampler every step: window gather + baseline "
                                         "correction + robust scaling + clamp (one kernel) and the speech rows' gather, on a stream of "
                                         "their own one batch ahead (gwilliams2022.py:129-142,640-661; get_dataloaders.py:48-87)"}

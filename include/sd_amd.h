@@ -28,11 +28,12 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 3   /* 2: sda_conv_args gained glu_out / glu_gate, sda_pack_desc gained glu_tile, flag 16384 = SDA_CONV_FLAT_TILES;
+#define SDA_ABI_VERSION 4   /* 2: sda_conv_args gained glu_out / glu_gate, sda_pack_desc gained glu_tile, flag 16384 = SDA_CONV_FLAT_TILES;
                                (still 2, should have been bumped: sda_wgrad_args.acc_scale, new arguments of sda_bn_finalize,
                                sda_clip_logits_stats and sda_clip_grad, new entries sda_clip_dz / sda_param_gemm / sda_copy3d)
                                3: sda_wgrad_args.flags (SDA_WGRAD_FLAT_ROWS), sda_stream_create_cumask / sda_stream_create_priority / sda_stream_destroy, sda_sim_gemm / sda_sim_gemm_ksplit,
-                               conv3_flat takes x_pitch == w_pitch only */
+                               conv3_flat takes x_pitch == w_pitch only
+                               4: sda_fill_zero, sda_gather_samples, sda_clip_merge_rows */
 #define SDA_ROW_PAD 16
 #define SDA_CH_ALIGN 64
 
@@ -226,6 +227,14 @@ int sda_reduce_scratch_floats(int Cp);
 /* Zero the rows of an RL buffer that kernels never write: the SDA_ROW_PAD rows in front of each of the B samples and the
  * slack behind the last one (a buffer whose valid rows a kernel is about to fill needs nothing else initialised) */
 int sda_zero_pad_rows(void* buf, int B, int T, int Cp, int dtype, void* stream);
+/* nbytes zero bytes at p (16-byte aligned): the fresh zero gradients a backward hands out (conv biases in front of a training-mode
+ * BatchNorm: autograd's zero, speech_decoding/models.py:135,143) without a framework fill kernel in the step */
+int sda_fill_zero(void* p, long nbytes, void* stream);
+/* dst sample b = table sample idx[b] (idx: B int64 on the device), samples of sample_bytes contiguous bytes (a multiple of 16).
+ * The resident-feed form of `Y = dataset.Y[batch indices]` (gwilliams2022.py:129-142 hands out one embedding per item): with the
+ * embedding table kept in row layout (a sample = (T + SDA_ROW_PAD) * Cp elements, pad rows included) the gathered batch IS the
+ * packed row-layout operand of the loss — no index_select + sda_pack_rows pair per step */
+int sda_gather_samples(const void* table, const long* idx, void* dst, int B, long sample_bytes, void* stream);
 /* out[i] = a[i] * b[0], i < n (device scalars: e.g. d loss / d temp times the incoming gradient) */
 int sda_scalar_mul(const float* a, const float* b, float* out, int n, void* stream);
 
@@ -341,6 +350,11 @@ int sda_clip_dz(const void* G, long g_pitch, const void* Y, const void* Z, void*
                 const float* out_scale, int Bm, int Bn, long row_elems, int dtype, void* stream);
 /* cnt[i] = #{local j : logits[i][j] beats diag[i]} (ties: lower global index wins) — Classifier ranks */
 int sda_clip_ranks(const float* logits, const float* diag, int32_t* cnt, int Bm, int Bn, int col0, void* stream);
+/* data parallelism: merge of the per-rank row statistics of the loss (all = the all-gathered [world][3][Bg] table of
+ * (row max, row sum exp(l - max), positive's logit or 0) over each rank's block of brain columns): lse[i] = log-sum-exp of global
+ * speech row i over the columns of ALL ranks, diag[i] = its positive's logit (utils/loss.py:79's two cross-entropies at the
+ * global batch) */
+int sda_clip_merge_rows(const float* all, int world, int Bg, float* lse, float* diag, void* stream);
 int sda_device_count(void);
 /* CU partitions (diagnostic / scheduling experiments): a HIP stream whose kernels run only on the CUs set in `mask` (bit i of
  * word i / 32 = CU i in the runtime's numbering; hipExtStreamCreateWithCUMask), and the CU count persistent grids launched

@@ -131,8 +131,7 @@ __device__ __forceinline__ void flat1_tile(const sda_conv_args& a, unsigned char
       constexpr int m = decltype(mc)::value;
       uint4 af_next = af;
       if constexpr (m + 1 < MREP) af_next = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow0 + (m + 1) * 16, lq));
-#pragma unroll
-      for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af, bf[n], acc[m][n]);
+      mma16_row<E, NREP>(af, bf, acc[m]);
       // the DMA pieces go BETWEEN the MFMA rows: the wave's issue slot is free while the matrix pipe works through the MFMAs queued before it
       if constexpr (MODE == 0) {
         if (!no_dma) {

@@ -263,8 +263,7 @@ __device__ __forceinline__ void flat_tile(const sda_conv_args& a, unsigned char*
         if constexpr (DIAG == 3) { asm volatile("" : "+v"(af_next.x)); }
         else if constexpr (m + 1 < MREP) af_next = *reinterpret_cast<const uint4*>(xs + lds_sw64(xrow + (m + 1) * 16, lq));
         else { if (!last_phase) af_next = *reinterpret_cast<const uint4*>(xs_n + lds_sw64(xrow_n, lq)); }
-#pragma unroll
-        for (int n = 0; n < F_NREP; ++n) acc[m][n] = mma16<E>(af, bf[n], acc[m][n]);
+        mma16_row<E, F_NREP>(af, bf, acc[m]);
         // this phase's DMA pieces go BETWEEN the MFMA rows (the wave's issue slot is free while the matrix pipe works
         // through the MFMAs queued before it)
         if constexpr (MODE < 2 && DIAG < 2) {
@@ -591,6 +590,13 @@ __global__ __launch_bounds__(256, 2) void conv3_flat_kernel(const sda_conv_args 
   if constexpr (DIAG == 1) {       // only 256-row tiles are stamped; sums land behind the wall-clock stamps of this workgroup
     if (dbg && c.tid == 0) { for (int i = 0; i < 5; ++i) dbg[16 + i] = 0; }
     for (int p = 0; p < pairs; ++p, u += 2) { flat_tile<E, BN, 8, RESX, 1>(a, smem, c, (long)u * F_UNIT, u, dbg ? dbg + 16 : nullptr); stamp(); }
+    return;
+  }
+  if constexpr (sizeof(E) == 4) {
+    // fp32 storage (the exact path): 128-row tiles only — 64 x 80 per wave, 80 accumulator registers.  The 256-row tile's 160
+    // accumulators leave the fp32 instantiation (16-deep K-steps: twice the fragment traffic per MFMA row, 40-KB epilogue
+    // slices read per thread) some 300 registers short, spilled inside the K loop.
+    for (; u < u_end; ++u) { flat_tile<E, BN, 4, RESX, 0, GLU>(a, smem, c, (long)u * F_UNIT, u); __builtin_amdgcn_s_setprio(0); }
     return;
   }
   if (lead) { flat_tile<E, BN, 4, RESX, (DIAG > 1 ? DIAG : 0), GLU>(a, smem, c, (long)u * F_UNIT, u); ++u; stamp(); __builtin_amdgcn_s_setprio(0); }

@@ -198,8 +198,7 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
     between();                                          // next slab's DMA issue, hidden behind the MFMAs below
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af[m], bf[n], acc[m][n]);
+      mma16_row<E, NREP>(af[m], bf, acc[m]);
   };
   // The same with the next slab's LDS-DMA pieces spread over the tap: `piece(m)` runs after the m-th row of MFMAs (an issue
   // costs ~100 cycles of the wave's issue slot; behind queued MFMAs the matrix pipe keeps working through it — one burst of
@@ -225,8 +224,7 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
           for (int n = 0; n < NREP; ++n)
             bf[(tap + 1) & 1][n] = *reinterpret_cast<const uint4*>(ws + lds_sw64((tap + 1) * TILE_CO + wrow0 + n * 16, lq));
         }
-#pragma unroll
-        for (int n = 0; n < NREP; ++n) acc[m][n] = mma16<E>(af, bf[tap & 1][n], acc[m][n]);
+        mma16_row<E, NREP>(af, bf[tap & 1], acc[m]);
         piece(tap, m);
         af = af_next;
       }

@@ -845,6 +845,25 @@ __global__ __launch_bounds__(256) void zero_pad_rows_kernel(uint4* __restrict__ 
     buf[v] = make_uint4(0u, 0u, 0u, 0u);
   }
 }
+// zero `n16` 16-byte vectors + `tail` trailing bytes
+__global__ __launch_bounds__(256) void fill_zero_kernel(uint4* __restrict__ p, long n16, int tail) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) reinterpret_cast<unsigned char*>(p + n16)[threadIdx.x] = 0;
+}
+// dst sample b = table sample idx[b]: whole samples of `vecs` 16-byte vectors (a row-layout sample is (T + PAD) * Cp contiguous
+// elements, pad rows included, so a gathered batch IS a row-layout buffer); blockIdx.y = b
+__global__ __launch_bounds__(256) void gather_samples_kernel(const uint4* __restrict__ table, const long* __restrict__ idx,
+                                                             uint4* __restrict__ dst, long vecs) {
+  const uint4* __restrict__ src = table + (size_t)idx[blockIdx.y] * vecs;
+  uint4* __restrict__ out = dst + (size_t)blockIdx.y * vecs;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long step = (long)gridDim.x * 256;
+  for (; i + 3 * step < vecs; i += 4 * step) {            // four loads in flight per lane
+    const uint4 a = src[i], b = src[i + step], c = src[i + 2 * step], d = src[i + 3 * step];
+    out[i] = a; out[i + step] = b; out[i + 2 * step] = c; out[i + 3 * step] = d;
+  }
+  for (; i < vecs; i += step) out[i] = src[i];
+}
 __global__ void scalar_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] * b[0];
@@ -859,6 +878,30 @@ extern "C" int sda_zero_pad_rows(void* buf, int B, int T, int Cp, int dtype, voi
   hipLaunchKernelGGL(zero_pad_rows_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream,
                      (uint4*)buf, B, rows_tp(T), rows_alloc(B, T), row_vec);
   return check_launch("zero_pad_rows");
+}
+
+extern "C" int sda_fill_zero(void* p, long nbytes, void* stream) {
+  if (!p || nbytes < 1 || (reinterpret_cast<uintptr_t>(p) & 15)) { set_error("fill_zero: null, empty or unaligned buffer"); return -1; }
+  const long n16 = nbytes / 16;
+  const long blocks = (n16 + 255) / 256;
+  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0, (hipStream_t)stream,
+                     (uint4*)p, n16, (int)(nbytes - n16 * 16));
+  return check_launch("fill_zero");
+}
+
+extern "C" int sda_gather_samples(const void* table, const long* idx, void* dst, int B, long sample_bytes, void* stream) {
+  if (!table || !idx || !dst || B < 1 || sample_bytes < 16 || sample_bytes % 16 || (reinterpret_cast<uintptr_t>(table) & 15) ||
+      (reinterpret_cast<uintptr_t>(dst) & 15)) {
+    set_error("gather_samples: bad arguments (samples are whole 16-byte vectors)"); return -1;
+  }
+  const long vecs = sample_bytes / 16;
+  long bx = (vecs + 256 * 4 - 1) / (256 * 4);
+  const long want = (8L * launch_cus() + B - 1) / B;      // ~8 workgroups per CU over the whole batch
+  if (bx > want) bx = want;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(gather_samples_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)table, idx, (uint4*)dst, vecs);
+  return check_launch("gather_samples");
 }
 
 extern "C" int sda_scalar_mul(const float* a, const float* b, float* out, int n, void* stream) {

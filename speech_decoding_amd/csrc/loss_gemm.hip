@@ -16,6 +16,7 @@
 //     to become 16-byte row segments, Z is read and dZ written with 16 bytes per lane, each byte exactly once.
 // Y, Z and dZ are each touched once; bound: HBM (591 MB per launch at config 2 -> ~100 us at 6 TB/s).
 #include "sd_common.h"
+#include "flat_tile.h"
 #include "tr_operand.h"
 
 namespace sda {
@@ -217,12 +218,190 @@ int launch_dz(const void* G, long g_pitch, const void* Y, const void* Z, void* o
   return check_launch("clip_dz");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same gradient against MORE than 256 speech rows — a rank's block under data parallelism, where the contraction runs over
+// the GLOBAL batch (2048 or 4096 rows at the 8-GPU configurations): 404 GFLOP against 2.0 GB at 2048 x 256 x 385 024, i.e. a
+// matrix-core problem, and the coefficient matrix (1 MB) no longer fits a wave's registers.  One workgroup = 8 waves owns a
+// 256 (columns j) x 256 (embedding elements k) tile of dZ and walks the speech rows in 32-row K-steps through sim_gemm's ring:
+// four 32 KB LDS stages (the K-step's 32 x 512 B of Y and 32 x 512 B of G, both by LDS-DMA from a scalar base advanced once per
+// K-step plus two per-lane offsets), three K-steps in flight behind counted waits, one raw barrier per K-step (32 MFMAs per
+// wave).  Both operands are contracted over their ROW index, so all twelve fragments of a K-step are transposed reads
+// (ds_read_b64_tr_b16; 512-byte image rows, 32-byte groups XOR-ed with row & 7: conflict-free).  D[k][j] leaves four
+// consecutive k per lane; a 4 KB per-wave LDS patch turns 16 (j) x 64 (k) accumulator blocks into 128-byte row segments, so Z
+// is read and dZ written in whole cache lines, each byte once.  Workgroups are persistent (one per CU, 160 KB of LDS: the ring
+// and the patches side by side): the next tile's first three K-steps are requested BEFORE the epilogue of the current one.
+// wgrad_gemm's typed-output mode (128 x 128 tiles, two stages, fp32 staging epilogue) ran this shape at 527 TFLOP/s.
+constexpr int DT_TILE = 256;                          // columns j and embedding elements k per workgroup
+constexpr int DT_RB = DT_TILE * 2;                    // image row bytes
+constexpr int DT_OP = 32 * DT_RB;                     // 16 KB per operand and K-step
+constexpr int DT_STAGE = 2 * DT_OP;                   // Y image, then G image
+constexpr int DT_NS = 4;
+constexpr int DT_PATCH = 16 * 64 * 4;                 // per wave: 16 rows j x 64 columns k, fp32
+constexpr int DT_LDS = DT_NS * DT_STAGE + 8 * DT_PATCH;   // 163 840 B
+
+template <typename E>
+__global__ __launch_bounds__(512, 2) void clip_dz_tiles_kernel(const E* __restrict__ G, const long g_pitch, const E* __restrict__ Y,
+                                                               const E* __restrict__ Z, E* __restrict__ out,
+                                                               const float* __restrict__ cscale, const float* __restrict__ rscale,
+                                                               const float* __restrict__ out_scale, const int Bm, const int Bn,
+                                                               const long row_elems, const int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wid & 1, wj = wid >> 1;               // wave tile: k [wk * 128, +128) x j [wj * 64, +64)
+  const int lr = lane & 15, lq = lane >> 4;
+  const int j0 = blockIdx.y * DT_TILE;
+  const int nks = Bm >> 5;                             // K-steps of 32 speech rows (Bm % 32 == 0: the launcher checks)
+
+  // LDS-DMA pieces: one wave instruction = 2 image rows x 512 B, lane-linear; the bank swizzle goes on the SOURCE chunk.
+  // Wave w fetches pieces w and w + 8 of either image.  Columns of G past its pitch (a tile wider than the matrix) are moved
+  // inside: they feed outputs that are never stored.
+  const int prow = lane >> 5, pchunk = lane & 31;
+  uint32_t yoff[2], goff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = (wid + 8 * h) * 2 + prow;
+    const int sw = pchunk ^ chunk_xor<E, DT_RB>(r);
+    long jc = (long)j0 + sw * 8;
+    if (jc + 8 > g_pitch) jc = g_pitch - 8;
+    yoff[h] = (uint32_t)(((size_t)r * row_elems + (size_t)sw * 8) * sizeof(E));
+    goff[h] = (uint32_t)(((size_t)r * g_pitch + (size_t)jc) * sizeof(E));
+  }
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const size_t ystep = (size_t)32 * row_elems, gstep = (size_t)32 * g_pitch;
+  const E* ys = Y;
+  const E* gs = G;
+  auto issue = [&](int buf, int q) {                   // this wave's q-th piece of the K-step `ys` / `gs` point at, into stage `buf`
+    const uint32_t dst = lds_base + buf * DT_STAGE + (wid + 8 * (q & 1)) * 1024;
+    if (q < 2) lds_dma16_lean<false>(ys, yoff[q & 1], dst);
+    else lds_dma16_lean<false>(gs, goff[q & 1], dst + DT_OP);
+  };
+  auto prologue = [&](int tile) {
+    ys = Y + (size_t)tile * DT_TILE;
+    gs = G;
+#pragma unroll
+    for (int p = 0; p < DT_NS - 1; ++p) {
+      if (p < nks) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue(p, q);
+        ys += ystep; gs += gstep;
+      }
+    }
+  };
+  // transposed fragment reads: per-lane offsets, fixed for the kernel (a K-step is one stage: row 0 of either image)
+  uint32_t a_off[8], b_off[4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) a_off[a] = tr_offset_bf16<DT_RB>(0, wk * 128 + a * 16, lane);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) b_off[b] = DT_OP + tr_offset_bf16<DT_RB>(0, wj * 64 + b * 16, lane);
+
+  float* patch = reinterpret_cast<float*>(smem + DT_NS * DT_STAGE + wid * DT_PATCH);
+  const float os = out_scale ? out_scale[0] : 1.f;
+  const int jr = lane >> 3, kc = (lane & 7) * 8;       // epilogue pass: row of the patch (+ 8 on the second pass), 8 consecutive k
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) prologue(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    for (int s = 0; s < nks; ++s) {
+      const int younger = nks - 1 - s;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const bool more = s + (DT_NS - 1) < nks;
+      const int nxt = cur == 0 ? DT_NS - 1 : cur - 1;
+      const unsigned char* img = smem + cur * DT_STAGE;
+      uint4 bf[4], af[8];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = tr_read_bf16<DT_RB>(img + b_off[b]);
+#pragma unroll
+      for (int a = 0; a < 8; ++a) af[a] = tr_read_bf16<DT_RB>(img + a_off[a]);
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mma16<E>(af[a], bf[b], acc[a][b]);
+        if ((a & 1) && more) issue(nxt, a >> 1);
+      }
+      if (more) { ys += ystep; gs += gstep; }
+      cur = cur == DT_NS - 1 ? 0 : cur + 1;
+    }
+    __syncthreads();                                    // every wave has read its last fragments: the ring is free
+    const int next = tile + (int)gridDim.x;
+    if (next < ntiles) prologue(next);                  // lands while the epilogue below runs
+    // ---- epilogue.  acc[a][b]: k = wk * 128 + a * 16 + 4 * lq + r, j = wj * 64 + b * 16 + lr.  Per (b, half): four fragments
+    // -> patch[j = lr][64 k] (16-byte chunks XOR-ed with the row), then lane -> (row, 8 consecutive k): 16 bytes of Z in, 16 out
+    const long kbase = (long)tile * DT_TILE + wk * 128;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+          const int ch = (a4 * 4 + lq) ^ lr;
+          *reinterpret_cast<f32x4*>(patch + lr * 64 + ch * 4) = acc[half * 4 + a4][b];
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int row = jr + 8 * pass;
+          const int j = j0 + wj * 64 + b * 16 + row;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + row * 64 + (((kc >> 2)) ^ row) * 4);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + row * 64 + (((kc >> 2) + 1) ^ row) * 4);
+          if (j < Bn) {
+            const size_t off = (size_t)j * row_elems + kbase + half * 64 + kc;
+            const float cs = cscale ? cscale[j] : 1.f, rs = rscale[j];
+            float z[8], v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            Vec16<E>::load(Z + off, z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = os * (cs * v[e] - rs * z[e]);
+            Vec16<E>::store(out + off, v);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next tile's first K-steps (and this epilogue's own traffic)
+  }
+}
+
+template <typename E>
+int launch_dz_tiles(const void* G, long g_pitch, const void* Y, const void* Z, void* out, const float* cscale, const float* rscale,
+                    const float* out_scale, int Bm, int Bn, long row_elems, hipStream_t st) {
+  static unsigned long long attr_done = 0;        // per device
+  auto kern = clip_dz_tiles_kernel<E>;
+  if (first_use_on_device(attr_done)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS) != hipSuccess) {
+      set_error("clip_dz: cannot reserve %d bytes of LDS", DT_LDS);
+      return -3;
+    }
+  }
+  const int ntiles = (int)(row_elems / DT_TILE);
+  const int jblocks = (Bn + DT_TILE - 1) / DT_TILE;
+  int gx = launch_cus() / jblocks;                     // one persistent workgroup per CU in all
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = ntiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)jblocks), dim3(512), DT_LDS, st, (const E*)G, g_pitch, (const E*)Y, (const E*)Z,
+                     (E*)out, cscale, rscale, out_scale, Bm, Bn, row_elems, ntiles);
+  return check_launch("clip_dz(tiles)");
+}
+
+// shapes of the tiled form: whole 32-row K-steps, whole 256-element column tiles, per-lane offsets inside 32 bits
+static bool dz_tiles_ok(int Bm, int Bn, long row_elems, int dtype) {
+  return (dtype == SDA_BF16 || dtype == SDA_F16) && Bm > DZ_ROWS && Bm % 32 == 0 && Bn >= 1 && row_elems >= DT_TILE &&
+         row_elems % DT_TILE == 0 && row_elems / DT_TILE < 0x7fffffffL && 32L * row_elems * 2 < (1L << 32);
+}
+
 }  // namespace
 }  // namespace sda
 
 using namespace sda;
 
 extern "C" int sda_clip_dz_supported(int Bm, int Bn, long row_elems, int dtype) {
+  if (dz_tiles_ok(Bm, Bn, row_elems, dtype)) return 1;
   return (dtype == SDA_BF16 || dtype == SDA_F16) && Bm >= 1 && Bm <= DZ_ROWS && Bn >= 1 && row_elems >= DZ_KT && row_elems % DZ_KT == 0 &&
          row_elems / DZ_KT < 0x7fffffffL;
 }
@@ -231,10 +410,16 @@ extern "C" int sda_clip_dz(const void* G, long g_pitch, const void* Y, const voi
                            const float* rscale, const float* out_scale, int Bm, int Bn, long row_elems, int dtype, void* stream) {
   if (!G || !Y || !Z || !out || !rscale || g_pitch < Bn) { set_error("clip_dz: bad arguments"); return -1; }
   if (!sda_clip_dz_supported(Bm, Bn, row_elems, dtype)) {
-    set_error("clip_dz: needs a 16-bit dtype, Bm <= %d and row_elems %% %d == 0 (use sda_wgrad_gemm's typed output otherwise)", DZ_ROWS, DZ_KT);
+    set_error("clip_dz: needs a 16-bit dtype and either Bm <= %d with row_elems %% %d == 0, or Bm %% 32 == 0 with row_elems %% %d == 0 "
+              "(use sda_wgrad_gemm's typed output otherwise)", DZ_ROWS, DZ_KT, DT_TILE);
     return -1;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (dz_tiles_ok(Bm, Bn, row_elems, dtype)) {
+    if (g_pitch % 8 || g_pitch < 8) { set_error("clip_dz: the coefficient matrix's pitch must be a multiple of 8 elements"); return -1; }
+    if (dtype == SDA_BF16) return launch_dz_tiles<uint16_t>(G, g_pitch, Y, Z, out, cscale, rscale, out_scale, Bm, Bn, row_elems, st);
+    return launch_dz_tiles<half_t>(G, g_pitch, Y, Z, out, cscale, rscale, out_scale, Bm, Bn, row_elems, st);
+  }
   if (dtype == SDA_BF16) return launch_dz<uint16_t>(G, g_pitch, Y, Z, out, cscale, rscale, out_scale, Bm, Bn, row_elems, st);
   return launch_dz<half_t>(G, g_pitch, Y, Z, out, cscale, rscale, out_scale, Bm, Bn, row_elems, st);
 }

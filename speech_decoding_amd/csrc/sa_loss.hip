@@ -327,6 +327,33 @@ extern "C" int sda_sa_weights_backward(const float* dWd, const float* W, const f
   return check_launch("sa_weights_backward");
 }
 
+namespace sda {
+// Cross-rank merge of the loss's row statistics: every rank holds, for every GLOBAL speech row, (max, sum exp(l - max))
+// over ITS block of brain columns and the positive's logit (zero where the positive lives on another rank); `all` = the
+// all-gathered table [world][3][Bg].  lse[i] = M + log sum_r s_r exp(m_r - M), M = max_r m_r; diag[i] = sum_r d_r — in rank
+// order, as distributed.combine_row_stats (the torch form, kept for the CPU tests) computes them.
+__global__ __launch_bounds__(256) void clip_merge_rows_kernel(const float* __restrict__ all, int world, int Bg,
+                                                              float* __restrict__ lse, float* __restrict__ diag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Bg) return;
+  float M = -INFINITY;
+  for (int r = 0; r < world; ++r) M = fmaxf(M, all[((size_t)r * 3 + 0) * Bg + i]);
+  float S = 0.f, D = 0.f;
+  for (int r = 0; r < world; ++r) {
+    S += all[((size_t)r * 3 + 1) * Bg + i] * expf(all[((size_t)r * 3 + 0) * Bg + i] - M);
+    D += all[((size_t)r * 3 + 2) * Bg + i];
+  }
+  lse[i] = M + logf(S);
+  diag[i] = D;
+}
+}  // namespace sda
+
+extern "C" int sda_clip_merge_rows(const float* all, int world, int Bg, float* lse, float* diag, void* stream) {
+  if (!all || !lse || !diag || world < 1 || Bg < 1) { set_error("clip_merge_rows: bad arguments"); return -1; }
+  hipLaunchKernelGGL(sda::clip_merge_rows_kernel, dim3((Bg + 255) / 256), dim3(256), 0, (hipStream_t)stream, all, world, Bg, lse, diag);
+  return check_launch("clip_merge_rows");
+}
+
 extern "C" int sda_clip_logits_stats(const float* S, long s_pitch, const float* ysq, const float* zsq, const float* temp,
                                      float* logits, float* row_max, float* row_sum, float* col_lse, float* diag,
                                      float* row_lse, int Bm, int Bn, int col0, void* stream) {

@@ -183,6 +183,50 @@ template <> __device__ inline f32x4 mma16<float>(const uint4& a, const uint4& b,
   return c;
 }
 
+// One MFMA row: acc[n] += a x b[n] for n < N.  16-bit types: N MFMAs.  fp32: the 16-deep K-step is four 16x16x4 MFMAs per
+// accumulator — issued j-OUTER, n-inner, so that consecutive MFMAs are independent and each accumulator is updated in place
+// (the accumulation order per accumulator is unchanged: j = 0, 1, 2, 3 — bit-equal results).  Written n-outer (four
+// back-to-back MFMAs chained through one accumulator, as mma16<float> does on its own) hipcc routes every chain through a
+// temporary register quad: two of every four MFMAs read a SrcC that is not exactly the previous MFMA's vDst, and the matrix
+// pipe waits out the dependency (cdna3 ISA, XDL write -> SrcC read, 8 passes) — the exact path's k = 3 convs sat at 57 % of
+// the fp32 matrix peak.
+template <typename E, int N> __device__ __forceinline__ void mma16_row(const uint4& a, const uint4 (&b)[N], f32x4 (&acc)[N]) {
+  if constexpr (sizeof(E) == 4) {
+    const uint32_t av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const uint32_t bj = j == 0 ? b[n].x : (j == 1 ? b[n].y : (j == 2 ? b[n].z : b[n].w));
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[j]), __uint_as_float(bj), acc[n], 0, 0, 0);
+      }
+  } else {
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = mma16<E>(a, b[n], acc[n]);
+  }
+}
+// The same for an M x N block of accumulators (wgrad_gemm: M row fragments against N column fragments)
+template <typename E, int M, int N> __device__ __forceinline__ void mma16_block(const uint4 (&a)[M], const uint4 (&b)[N], f32x4 (&acc)[M][N]) {
+  if constexpr (sizeof(E) == 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const uint32_t aj = j == 0 ? a[m].x : (j == 1 ? a[m].y : (j == 2 ? a[m].z : a[m].w));
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+          const uint32_t bj = j == 0 ? b[n].x : (j == 1 ? b[n].y : (j == 2 ? b[n].z : b[n].w));
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(aj), __uint_as_float(bj), acc[m][n], 0, 0, 0);
+        }
+      }
+  } else {
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc[m][n] = mma16<E>(a[m], b[n], acc[m][n]);
+  }
+}
+
 // GELU (erf form, F.gelu default — models.py:158,161,194,195) and its derivative, by storage type.
 // fp32 storage: libm erff, the exact path.  16-bit storage: the normal tail 0.5*erfc(|x|/sqrt2) by Abramowitz-Stegun
 // 26.2.17 (|error| <= 7.5e-8 absolute; 2^-9 / 2^-11 is the storage resolution) — one v_rcp + one v_exp shared by the

@@ -9,13 +9,14 @@ namespace sda {
 // LDS-DMA pieces; bank conflicts of the TRANSPOSED operand reads are removed by XOR-ing the 16-byte chunk
 // index with a function of the row (applied to the DMA source address and to the read address alike):
 //   bf16 (ds_read_b64_tr_b16, a 32-lane half reads 8 consecutive rows x 32 B):  32-byte groups
-//       RB = 128: group ^= (row >> 1) & 3     RB = 256: group ^= row & 7     RB = 320: group ^= (row >> 2) & 1
+//       RB = 128: group ^= (row >> 1) & 3     RB = 256, 512: group ^= row & 7     RB = 320: group ^= (row >> 2) & 1
 //   fp32 (ds_read_b32, a half reads 2 consecutive rows x 64 B):  64-byte groups, group ^= row & 1
 template <typename E, int RB> __device__ inline int chunk_xor(int row) {
   if (sizeof(E) == 4) return (row & 1) << 2;
   if (RB == 128) return ((row >> 1) & 3) << 1;
   if (RB == 256) return (row & 7) << 1;
   if (RB == 320) return ((row >> 2) & 1) << 1;
+  if (RB == 512) return (row & 7) << 1;                         // (row stride = 0 mod 256 B: the eight rows of a half take eight distinct 32-byte groups)
   return 0;
 }
 

@@ -346,10 +346,7 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
       if constexpr (PIPE && tap == KS - 1 && kk + 1 < NKK) read_a(std::integral_constant<int, kk + 1>{}, af_n);
       // (hipcc sinks the last two groups' reads below the MFMAs of the group before them; pinning them with a scheduling
       // barrier — 235 registers, every group's fragments in flight a group ahead — measured 7.05-7.08 vs 7.02-7.09 ms: not kept)
-#pragma unroll
-      for (int m = 0; m < MREP; ++m)
-#pragma unroll
-        for (int n = 0; n < NREP; ++n) acc[tap][m][n] = mma16<E>(af[m], bf[n], acc[tap][m][n]);
+      mma16_block<E, MREP, NREP>(af, bf, acc[tap]);
       if (fast) {
         wg_static_for<g * PER_GRP, (g + 1) * PER_GRP < NPW ? (g + 1) * PER_GRP : NPW>(issue_piece);
       }

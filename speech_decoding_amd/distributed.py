@@ -186,10 +186,19 @@ def merge_row_softmax_stats(row_max: torch.Tensor, row_sum: torch.Tensor, group=
     if group is not None and dist.is_initialized():     # None = stay local
         world = dist.get_world_size(group)
         parts = [row_max, row_sum] + ([diag] if diag is not None else [])
-        mine = torch.stack([p.to(torch.float32) for p in parts]).contiguous()             # (k, Bg)
+        n = row_max.numel()
+        if (len(parts) == 3 and all(p.dtype == torch.float32 and p.is_contiguous() for p in parts)
+                and row_sum.data_ptr() == row_max.data_ptr() + 4 * n and diag.data_ptr() == row_max.data_ptr() + 8 * n):
+            mine = row_max.as_strided((3, n), (n, 1))                 # the three are rows of one buffer (ops.clip_logits_stats)
+        else:
+            mine = torch.stack([p.to(torch.float32) for p in parts]).contiguous()         # (k, Bg)
         flat = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=torch.float32, device=mine.device)
         dist.all_gather_into_tensor(flat, mine, group=group)          # concatenation along dim 0, rank-major
-        return combine_row_stats(flat.view(world, mine.shape[0], mine.shape[1]))
+        table = flat.view(world, mine.shape[0], mine.shape[1])
+        if table.is_cuda and table.shape[1] == 3:                     # one kernel instead of ~ten framework launches
+            from . import ops
+            return ops.clip_merge_rows(table)
+        return combine_row_stats(table)
     lse = row_max + torch.log(row_sum)
     return lse if diag is None else (lse, diag)
 

@@ -101,9 +101,9 @@ class EncoderEngine:
         self.forward_pair_tiles = True       # forward k = 3 convs (nothing competes for the CU's LDS there): two
                                              # tiles per workgroup share each weight slab — fewer LDS-DMA bytes per FLOP
         self.flat_tiles_forward = True       # k = 3 convs on the 256-row flat-tile kernel (conv3_flat.hip) where it applies
-        self.flat_tiles_forward_fp32 = False # ... for fp32 storage as well.  Off: conv3_flat's K loop (rebuilt in round 4 around the
-                                             # 16-bit kernels' register budget) spills ~300 registers in its fp32 instantiation —
-                                             # the exact path's step is 46.3 ms with it, 35.6 ms on the tile kernel (same box)
+        self.flat_tiles_forward_fp32 = True  # ... for fp32 storage as well (round 5: the fp32 instantiation runs 128-row tiles only —
+                                             # 80 accumulator registers per wave, no scratch; round 4's 256-row form spilled ~300
+                                             # registers into its K loop and the exact path went back to the tile kernel)
         self.flat_tile_options = 1024        # extra conv3_flat flags: 1024 = the second workgroup of a CU takes its 128-row tile FIRST
                                              # (the pair's epilogues — HBM bursts with the matrix pipe idle — fall at different
                                              # times: 68.6 -> 67.3 us per 320 -> 320 conv with the priority hand-over, round 4),
@@ -748,7 +748,7 @@ class EncoderEngine:
         # the gradient of the ten biases that feed a training-mode BatchNorm (identically zero): rows of ONE fresh zero buffer
         # per backward — autograd hands these views to the parameters' .grad, so a buffer kept across steps would alias
         # engine-owned memory into .grad (an in-place clip with a non-finite factor would poison every later step)
-        null_bias = torch.zeros((10, d.D2), dtype=torch.float32, device=dev) if ctx.training else None
+        null_bias = ops.zeros((10, d.D2), torch.float32, dev) if ctx.training else None
         flip = 0
         for k in range(4, -1, -1):
             cin, cin_p = (d.D1, d.D1p) if k == 0 else (d.D2, d.D2p)

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdamd.so")
 
-ABI_VERSION = 3          # SDA_ABI_VERSION of include/sd_amd.h this binding was written against
+ABI_VERSION = 4          # SDA_ABI_VERSION of include/sd_amd.h this binding was written against
 F32, BF16, F16 = 0, 1, 2
 ROW_PAD = 16
 CH_ALIGN = 64
@@ -125,6 +125,9 @@ SIGNATURES = {
     "sda_param_gemm": (i32, [C.POINTER(PgemmArgs), vp]),
     "sda_zero_pad_rows": (i32, [vp, i32, i32, i32, i32, vp]),
     "sda_scalar_mul": (i32, [vp, vp, vp, i32, vp]),
+    "sda_fill_zero": (i32, [vp, i64, vp]),
+    "sda_gather_samples": (i32, [vp, vp, vp, i32, i64, vp]),
+    "sda_clip_merge_rows": (i32, [vp, i32, i32, vp, vp, vp]),
     "sda_copy3d": (i32, [vp, i64, i64, i64, vp, i64, i64, i64, i32, i32, i32, vp]),
 }
 

@@ -113,6 +113,36 @@ def zero_pad_rows(buf: torch.Tensor, B: int, T: int) -> torch.Tensor:
     return buf
 
 
+def zeros(shape, dtype, device) -> torch.Tensor:
+    """A fresh zero tensor filled by sda_fill_zero (no framework fill kernel inside the step)."""
+    out = torch.empty(shape, dtype=dtype, device=device)
+    if out.numel():
+        L.check(L.load().sda_fill_zero(out.data_ptr(), out.numel() * out.element_size(), _st()), "fill_zero")
+    return out
+
+
+def gather_samples(table: torch.Tensor, idx: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    """table: row-layout buffer holding N samples back to back ((N * Tp [+ slack], Cp), pad rows zero); idx: B int64 sample
+    indices on the device.  Returns a fresh row-layout buffer (rows_alloc(B, T), Cp) whose sample b is table sample idx[b]."""
+    _need_cuda(table, idx)
+    if idx.dtype != torch.int64 or idx.numel() != B:
+        raise L.SdaError("gather_samples: idx must hold B int64 indices")
+    Cp = table.shape[1]
+    out = new_rows_uninit(B, T, Cp, table.dtype, table.device)
+    L.check(L.load().sda_gather_samples(_p(table), _p(idx), _p(out), B, L.rows_tp(T) * Cp * table.element_size(), _st()), "gather_samples")
+    return out
+
+
+def clip_merge_rows(allp: torch.Tensor):
+    """allp: the all-gathered (world, 3, Bg) fp32 table of per-rank (row max, row sum exp, positive's logit) -> (lse, diag)."""
+    world, k, Bg = allp.shape
+    if k != 3 or allp.dtype != torch.float32 or not allp.is_contiguous():
+        raise L.SdaError("clip_merge_rows: a contiguous fp32 (world, 3, B_global) table")
+    out = torch.empty((2, Bg), dtype=torch.float32, device=allp.device)
+    L.check(L.load().sda_clip_merge_rows(_p(allp), world, Bg, _p(out[0]), _p(out[1]), _st()), "clip_merge_rows")
+    return out[0], out[1]
+
+
 def scalar_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a * b[0] for small fp32 device tensors (a: n elements, b: one)."""
     out = torch.empty_like(a)
@@ -715,10 +745,11 @@ def sa_weights_backward(dWd, W, mask, cosT, sinT, K2, bwd_table=None):
 def clip_logits_stats(S, ysq, zsq, temp, Bm, Bn, col0):
     dev = S.device
     logits = torch.empty((Bm, Bn), dtype=torch.float32, device=dev)
-    row_max = torch.empty(Bm, dtype=torch.float32, device=dev)
-    row_sum = torch.empty(Bm, dtype=torch.float32, device=dev)
+    # (row max, row sum, positive's logit) as the three rows of ONE buffer: under data parallelism that buffer is what the
+    # all-gather of the row statistics sends — no stack / copy in front of the collective
+    st3 = torch.empty((3, Bm), dtype=torch.float32, device=dev)
+    row_max, row_sum, diag = st3[0], st3[1], st3[2]                    # (diag: every row is written, zero where the positive lives elsewhere)
     col_lse = torch.empty(Bn, dtype=torch.float32, device=dev)
-    diag = torch.empty(Bm, dtype=torch.float32, device=dev)           # (every row is written: zero where the positive lives elsewhere)
     row_lse = torch.empty(Bm, dtype=torch.float32, device=dev)        # lse over THIS block of columns
     L.check(L.load().sda_clip_logits_stats(_p(S), S.shape[1], _p(ysq), _p(zsq), _p(temp), _p(logits), _p(row_max), _p(row_sum),
                                            _p(col_lse), _p(diag), _p(row_lse), Bm, Bn, col0, _st()), "clip_logits_stats")

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     L = lib.load()
     header = open(os.path.join(ROOT, "include", "sd_amd.h")).read()
     declared = int(re.search(r"#define\s+SDA_ABI_VERSION\s+(\d+)", header).group(1))
-    assert L.sda_abi_version() == declared == lib.ABI_VERSION == 3
+    assert L.sda_abi_version() == declared == lib.ABI_VERSION == 4
 
 
 def test_layout_helpers_agree_with_python_mirror(lib):
@@ -144,7 +144,7 @@ def test_no_kernel_of_the_library_spills_heavily(tmp_path):
     subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", "libsdamd.so"], cwd=work, check=True, capture_output=True)
     objs = [f for f in os.listdir(work) if "gfx950" in f]
     assert objs, "no gfx950 code object in the library"
-    known = re.compile(r"conv3_flat_kernelIf")          # fp32 storage on the flat-tile kernel: off every default path
+    known = re.compile(r"^$")                           # (round 5: none — conv3_flat's fp32 instantiation runs 128-row tiles only)
     seen, bad = 0, []
     for f in objs:
         notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", f], cwd=work, check=True, capture_output=True, text=True).stdout

@@ -697,7 +697,13 @@ def test_copy3d_strided(ops):
                                             (12, 12, 64, 40, torch.bfloat16),           # far below one tile of anything
                                             (100, 300, 128, 50, torch.float16),          # ragged batch, two column blocks of 256
                                             (256, 70, 64, 17, torch.float16),
-                                            (33, 64, 192, 9, torch.bfloat16)])
+                                            (33, 64, 192, 9, torch.bfloat16),
+                                            # more than 256 speech rows (a rank's block under data parallelism): the tiled form —
+                                            # 256 x 256 tiles, 32-row K-steps, both operands read transposed (round 5)
+                                            (512, 256, 64, 44, torch.bfloat16),          # 15 column tiles, one block of 256 columns
+                                            (288, 70, 128, 48, torch.float16),           # ragged columns: the tile is wider than G's pitch
+                                            (2048, 300, 64, 12, torch.bfloat16),         # two column blocks, 64 K-steps
+                                            (320, 256, 256, 20, torch.float16)])
 def test_clip_dz_streaming_kernel_against_fp64(ops, Bm, Bn, F, T, dtype):
     """dZ[j] = dloss * (cscale[j] * sum_i G[i][j] Y[i] - rscale[j] Z[j]) on row-layout embeddings: against fp64 on the same
     rounded operands, and against the general kernel it replaces on one GPU (wgrad_gemm's typed output)."""
@@ -773,3 +779,49 @@ def test_priority_stream_entry_point(ops):
         assert t.cpu().tolist() == list(range(7))
     with pytest.raises(L.SdaError):
         ops.stream_create_priority(5)
+
+
+# ------------------------------------------------------------------------------------------------------ ABI 4 (round 5)
+def test_fill_zero(ops):
+    for shape in [(10, 320), (3,), (1, 7), (4097,)]:
+        t = ops.zeros(shape, torch.float32, DEV)
+        assert tuple(t.shape) == shape and float(t.abs().max()) == 0.0
+    big = torch.full((5000,), 3.0, device=DEV)
+    from speech_decoding_amd import lib as L
+    L.check(L.load().sda_fill_zero(big.data_ptr() + 16 * 4, 4 * 1001, None if False else torch.cuda.current_stream().cuda_stream), "fill_zero")
+    ref = torch.full((5000,), 3.0)
+    ref[16:16 + 1001] = 0
+    assert torch.equal(big.cpu(), ref)                 # nothing before the start, nothing behind the last byte
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gather_samples_is_index_select_plus_pack(ops, dtype):
+    """The resident feed's embedding gather (data.ResidentSegmentFeed.pack_embeddings): a batch gathered from the row-layout
+    table equals sda_pack_rows of the fp32 batch — bit for bit, pad rows and slack included."""
+    from speech_decoding_amd import lib as L
+    N, F, T, B = 23, 96, 52, 9
+    g = torch.Generator().manual_seed(3)
+    Y = torch.randn(N, F, T, generator=g)
+    Tp, Fp = L.rows_tp(T), L.pad_channels(F)
+    table = torch.zeros((N * Tp + L.rows_alloc(1, T) - Tp, Fp), dtype=dtype, device=DEV)
+    for k in range(0, N, 7):
+        ops.pack_rows(Y[k: k + 7].to(DEV), table[k * Tp:])
+    idx = torch.tensor([5, 0, 22, 22, 7, 13, 1, 21, 5])
+    got = ops.gather_samples(table, idx.to(DEV), B, T)
+    want = to_rows(ops, Y[idx], dtype)
+    assert got.shape == want.shape and torch.equal(got.view(torch.uint8).cpu(), want.view(torch.uint8).cpu())
+    view = ops.rows_view(got, B, F, T)
+    assert torch.equal(view.float().cpu(), Y[idx].to(dtype).float())
+
+
+def test_clip_merge_rows_equals_the_torch_merge(ops):
+    from speech_decoding_amd.distributed import combine_row_stats
+    g = torch.Generator().manual_seed(11)
+    for world, Bg in [(1, 40), (8, 2048), (3, 257)]:
+        t = torch.randn(world, 3, Bg, generator=g)
+        t[:, 0] *= 30                                   # row maxima tens apart: exp(m_r - M) underflows for most ranks
+        t[:, 1] = t[:, 1].abs() + 1.0
+        lse, diag = ops.clip_merge_rows(t.to(DEV).contiguous())
+        wl, wd = combine_row_stats(t.double())
+        np.testing.assert_allclose(lse.cpu().numpy(), wl.numpy(), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(diag.cpu().numpy(), wd.numpy(), rtol=1e-6, atol=1e-6)

@@ -248,6 +248,32 @@ def test_resident_feed_batch_equals_the_host_pipeline():
     assert subj.tolist() == [int(feed.rec_subject[r]) for r in rec]
 
 
+def test_resident_feed_with_packed_embeddings_hands_out_the_loss_operand():
+    """pack_embeddings: the embedding table resident in row layout in the compute dtype — a batch's Y is a zero-copy view of one
+    gather kernel's output, equal to the fp32 batch rounded to that dtype, and CLIPLoss takes it without packing."""
+    from speech_decoding_amd.data import synthetic_resident_dataset
+    from speech_decoding_amd import loss as sda_loss, ops
+    args, _ = tiny_args("Gwilliams2022")
+    for dtype in (torch.bfloat16, torch.float32):
+        feed, _, _ = synthetic_resident_dataset(args, "cuda:0", n_segments=40, seed=1234)
+        plain = synthetic_resident_dataset(args, "cuda:0", n_segments=40, seed=1234)[0]
+        feed.pack_embeddings(dtype)
+        idx = np.array([3, 17, 17, 39, 0, 21, 8, 30, 11, 2, 5, 6])
+        X, Y, subj = feed.batch(idx)
+        X0, Y0, subj0 = plain.batch(idx)
+        assert torch.equal(X, X0) and torch.equal(subj, subj0) and Y.dtype == dtype and tuple(Y.shape) == tuple(Y0.shape)
+        assert torch.equal(Y.float().cpu(), Y0.to(dtype).float().cpu())
+        B, F, T = Y.shape
+        assert sda_loss._rows_base(Y, B, F, T, dtype) is not None          # recognised as a row-layout view: consumed in place
+        # the loss on the packed view equals the loss on the fp32 batch packed per call
+        from speech_decoding_amd import CLIPLoss
+        lossf = CLIPLoss(args).to("cuda:0")
+        Z = ops.rows_view(ops.gather_samples(feed._Yt, torch.tensor(idx[::-1].copy()).to("cuda:0"), B, T), B, F, T)   # any (B, F, T) embeddings
+        a = float(lossf(Y, Z))
+        b = float(lossf(Y0, Z))
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b))
+
+
 def test_training_driver_on_the_resident_feed(tmp_path, monkeypatch):
     """train.py with data=resident: sampler shard -> segment gather + collate on the GPU -> the training step; the loss
     comes down and the held-out split is ranked."""

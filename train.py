@@ -104,6 +104,7 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
         feed, train_idx, test_idx = synthetic_resident_dataset(args, device, n_segments=n_seg, seed=1234)
         updates = int(args.get("updates_per_epoch", max(1, len(train_idx) // int(args.batch_size))))
         epoch_no = [0]
+        pack_resident_embeddings = feed          # (packed once the encoder's compute dtype is known, below)
 
         def train_batches():
             sampler = ShardedRandomSampler(len(train_idx), int(args.batch_size), updates, rank, world, seed=4321 + epoch_no[0])
@@ -123,6 +124,8 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
         test_batch = data.test_batch
 
     brain_encoder = BrainEncoder(args).to(device)
+    if feeds_local_shards and "pack_resident_embeddings" in locals():
+        pack_resident_embeddings.pack_embeddings(brain_encoder.compute_dtype)      # Y batches arrive as the loss's packed operand
     classifier = Classifier(args)
     loss_func = CLIPLoss(args).to(device)
     loss_func.train()
