@@ -33,7 +33,8 @@ extern "C" {
                                sda_clip_logits_stats and sda_clip_grad, new entries sda_clip_dz / sda_param_gemm / sda_copy3d)
                                3: sda_wgrad_args.flags (SDA_WGRAD_FLAT_ROWS), sda_stream_create_cumask / sda_stream_create_priority / sda_stream_destroy, sda_sim_gemm / sda_sim_gemm_ksplit,
                                conv3_flat takes x_pitch == w_pitch only
-                               4: sda_fill_zero, sda_gather_samples, sda_clip_merge_rows */
+                               4: sda_fill_zero, sda_gather_samples, sda_clip_merge_rows; SDA_WGRAD_FLAT_ROWS with a sample permutation;
+                                  sda_clip_dz serves more than 256 speech rows (256 x 256 tiles) */
 #define SDA_ROW_PAD 16
 #define SDA_CH_ALIGN 64
 
@@ -265,9 +266,11 @@ int sda_colsum(const void* x, float* out, float* scratch /* sda_reduce_scratch_f
  * Output fp32 slabs [nseg][KS][Cout_p][Cin_p].  With out_e != NULL (KS must be 1, nseg 1) the result is
  * written as `dtype` rows instead:  out_e[co][ci] = out_scale * (acc_scale[co] * acc - rscale[co] * sub[co][ci])   (loss backward dZ). */
 /* sda_wgrad_args.flags */
-enum { SDA_WGRAD_FLAT_ROWS = 1  /* perm == NULL and dy is a row-layout buffer whose rows between samples (the SDA_ROW_PAD rows in
-                                   front of every sample) are zero: a segment is contracted as ONE run of rows, pad rows included
-                                   (they contribute nothing), in whole K-chunks — no partial chunk per sample */ };
+enum { SDA_WGRAD_FLAT_ROWS = 1  /* dy is a row-layout buffer whose rows between samples (the SDA_ROW_PAD rows in front of every
+                                   sample, the slack behind the last) are zero.  perm == NULL: a segment is contracted as ONE run of
+                                   rows, pad rows included (they contribute nothing), in whole K-chunks — no partial chunk per
+                                   sample.  perm != NULL (ABI 4): every SAMPLE is extended into the zero rows around it to whole
+                                   K-chunks (when (T rounded up to the chunk) - T <= 2 * SDA_ROW_PAD; ignored otherwise) */ };
 typedef struct sda_wgrad_args {
   const void* dy;       /* RL [rows][dy_pitch] */
   const void* x;        /* RL [rows][x_pitch] */

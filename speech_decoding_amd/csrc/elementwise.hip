@@ -321,6 +321,37 @@ __global__ void reduce_unpack_wgrad_kernel(const float* __restrict__ slabs, int 
   }
 }
 
+// The same on 16-byte loads (Cin % 4 == 0, slabs 16-byte aligned): a thread sums FOUR consecutive input channels of one
+// (tap, co) — a quarter of the threads, each with 8 x 16 B in flight; identical sums (each output adds its slabs in slab order)
+__global__ __launch_bounds__(256) void reduce_unpack_wgrad_vec_kernel(const float* __restrict__ slabs, int nslabs, float* __restrict__ dst,
+                                                                      int Cout, int Cin, int KS, int Cout_p, int Cin_p, int half, int half_p) {
+  const int cin4 = Cin >> 2;
+  const size_t total = (size_t)Cout * cin4 * KS;
+  const size_t slab = (size_t)KS * Cout_p * Cin_p;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t q = i;
+    const int c4 = q % cin4; q /= cin4;
+    const int co = q % Cout; q /= Cout;
+    const int tap = (int)q;
+    const size_t src = ((size_t)tap * Cout_p + glu_map(co, half, half_p)) * Cin_p + 4 * c4;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 8 <= nslabs; k += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(slabs + (size_t)(k + j) * slab + src);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sum.x += v[j].x; sum.y += v[j].y; sum.z += v[j].z; sum.w += v[j].w; }
+    }
+    for (; k < nslabs; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)k * slab + src);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    float* o = dst + ((size_t)co * Cin + 4 * c4) * KS + tap;
+    o[0] = sum.x; o[KS] = sum.y; o[2 * KS] = sum.z; o[3 * KS] = sum.w;
+  }
+}
+
 __global__ void pack_vector_kernel(const float* __restrict__ v, float* __restrict__ dst, int C, int Cp, int half, int half_p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Cp) return;
@@ -340,7 +371,9 @@ __global__ void unpack_vector_kernel(const float* __restrict__ g, float* __restr
 // 8*blockIdx.x + threadIdx.x on threads 0..7.
 __device__ inline void block_partial_sums(const float* __restrict__ partial, int n, int Cp, int cbase, bool two,
                                           double& s0, double& s1) {
-  __shared__ double sh[2][128][8];
+  // LDS image [which][j][thread]: every store and every load below is 64 consecutive 8-byte slots per wave (the channel-major
+  // [row group][8 channels] image of rounds 1-4 put 8 lanes on one bank: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.77)
+  __shared__ double sh[2][4][256];
   const int tx = threadIdx.x & 1, ty = threadIdx.x >> 1;
   double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
   const int c4 = cbase + tx * 4;
@@ -356,19 +389,27 @@ __device__ inline void block_partial_sums(const float* __restrict__ partial, int
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { sh[0][ty][tx * 4 + j] = a0[j]; sh[1][ty][tx * 4 + j] = a1[j]; }
+  for (int j = 0; j < 4; ++j) { sh[0][j][threadIdx.x] = a0[j]; sh[1][j][threadIdx.x] = a1[j]; }
   __syncthreads();
-  // 128 threads: (which, channel, eighth) -> 16 groups each, then a fixed shuffle tree over the eighths
+  // waves 0 and 1 (which = 0, 1): lane l adds, per j, the entries of threads l, l + 64, l + 128, l + 192 (same tx = l & 1), then
+  // a fixed shuffle tree over the 32 lanes of its parity: lanes 0 / 1 end with channels j / 4 + j
   __shared__ double res[2][8];
   if (threadIdx.x < 128) {
-    const int part = threadIdx.x & 7, c = (threadIdx.x >> 3) & 7, which = threadIdx.x >> 6;
-    double a = 0.0;
+    const int l = threadIdx.x & 63, which = threadIdx.x >> 6;
+    double a[4];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) a += sh[which][part * 16 + g][c];
-    a += __shfl_xor(a, 1);
-    a += __shfl_xor(a, 2);
-    a += __shfl_xor(a, 4);
-    if (part == 0) res[which][c] = a;
+    for (int j = 0; j < 4; ++j) {
+      a[j] = (sh[which][j][l] + sh[which][j][l + 64]) + (sh[which][j][l + 128] + sh[which][j][l + 192]);
+      a[j] += __shfl_xor(a[j], 2);
+      a[j] += __shfl_xor(a[j], 4);
+      a[j] += __shfl_xor(a[j], 8);
+      a[j] += __shfl_xor(a[j], 16);
+      a[j] += __shfl_xor(a[j], 32);
+    }
+    if (l < 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) res[which][l * 4 + j] = a[j];
+    }
   }
   __syncthreads();
   s0 = 0.0; s1 = 0.0;
@@ -513,18 +554,21 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
       }
     }
   }
+  // the per-row-group sums meet in LDS as [row group][which][16-byte quarter q][chunk] float4: a wave's store is 64 consecutive
+  // 16-byte slots (conflict-free; channel-major rows of CH floats per lane were 2- to 4-way conflicted)
   if (rg < RG) {
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      red[(rg * 2 + 0) * Cp + ch * CH + j] = a0[j];
-      red[(rg * 2 + 1) * Cp + ch * CH + j] = a1[j];
+    for (int q4 = 0; q4 < CH / 4; ++q4) {
+      *reinterpret_cast<float4*>(red + ((((rg * 2 + 0) * (CH / 4) + q4) * nch + ch) << 2)) = make_float4(a0[4 * q4], a0[4 * q4 + 1], a0[4 * q4 + 2], a0[4 * q4 + 3]);
+      *reinterpret_cast<float4*>(red + ((((rg * 2 + 1) * (CH / 4) + q4) * nch + ch) << 2)) = make_float4(a1[4 * q4], a1[4 * q4 + 1], a1[4 * q4 + 2], a1[4 * q4 + 3]);
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * Cp; i += 256) {
     const int which = i / Cp, c = i - which * Cp;
+    const int chc = c / CH, q4 = (c % CH) >> 2, e = c & 3;
     float s = 0.f;
-    for (int g = 0; g < RG; ++g) s += red[(g * 2 + which) * Cp + c];
+    for (int g = 0; g < RG; ++g) s += red[((((g * 2 + which) * (CH / 4) + q4) * nch + chc) << 2) + e];
     partial[((size_t)blockIdx.x * 2 + which) * Cp + c] = s;
   }
 }
@@ -585,18 +629,20 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
       }
     }
   }
+  // (LDS image as in col_reduce_kernel: [row group][which][quarter][chunk] float4, conflict-free stores)
   if (rg < RG) {
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      red[(rg * 2 + 0) * Ch + ch * CH + j] = a0[j];
-      red[(rg * 2 + 1) * Ch + ch * CH + j] = a1[j];
+    for (int q4 = 0; q4 < CH / 4; ++q4) {
+      *reinterpret_cast<float4*>(red + ((((rg * 2 + 0) * (CH / 4) + q4) * nch + ch) << 2)) = make_float4(a0[4 * q4], a0[4 * q4 + 1], a0[4 * q4 + 2], a0[4 * q4 + 3]);
+      *reinterpret_cast<float4*>(red + ((((rg * 2 + 1) * (CH / 4) + q4) * nch + ch) << 2)) = make_float4(a1[4 * q4], a1[4 * q4 + 1], a1[4 * q4 + 2], a1[4 * q4 + 3]);
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * Ch; i += 256) {
     const int which = i / Ch, c = i - which * Ch;
+    const int chc = c / CH, q4 = (c % CH) >> 2, e = c & 3;
     float sum = 0.f;
-    for (int g = 0; g < RG; ++g) sum += red[(g * 2 + which) * Ch + c];
+    for (int g = 0; g < RG; ++g) sum += red[((((g * 2 + which) * (CH / 4) + q4) * nch + chc) << 2) + e];
     partial[((size_t)blockIdx.x * 2 + which) * Ch + c] = sum;
   }
 }
@@ -1045,6 +1091,11 @@ extern "C" int sda_reduce_unpack_wgrad(const float* slabs, int nslabs, float* ds
                                        int Cin_p, int glu_half, int glu_half_p, void* stream) {
   if (!slabs || !dst || nslabs < 1) { set_error("reduce_unpack_wgrad: bad arguments"); return -1; }
   const size_t total = (size_t)Cout * Cin * KS;
+  if (Cin % 4 == 0 && Cin_p % 4 == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0) {
+    hipLaunchKernelGGL(reduce_unpack_wgrad_vec_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, dst,
+                       Cout, Cin, KS, Cout_p, Cin_p, glu_half, glu_half_p);
+    return check_launch("reduce_unpack_wgrad");
+  }
   hipLaunchKernelGGL(reduce_unpack_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, dst,
                      Cout, Cin, KS, Cout_p, Cin_p, glu_half, glu_half_p);
   return check_launch("reduce_unpack_wgrad");

@@ -15,6 +15,8 @@
 //   * the epilogue is per wave (no workgroup barrier): 16 x 32 accumulator blocks pass through a 2 KB private LDS patch
 //     to become 16-byte row segments, Z is read and dZ written with 16 bytes per lane, each byte exactly once.
 // Y, Z and dZ are each touched once; bound: HBM (591 MB per launch at config 2 -> ~100 us at 6 TB/s).
+#include <cstdlib>
+
 #include "sd_common.h"
 #include "flat_tile.h"
 #include "tr_operand.h"
@@ -391,7 +393,9 @@ int launch_dz_tiles(const void* G, long g_pitch, const void* Y, const void* Z, v
 
 // shapes of the tiled form: whole 32-row K-steps, whole 256-element column tiles, per-lane offsets inside 32 bits
 static bool dz_tiles_ok(int Bm, int Bn, long row_elems, int dtype) {
-  return (dtype == SDA_BF16 || dtype == SDA_F16) && Bm > DZ_ROWS && Bm % 32 == 0 && Bn >= 1 && row_elems >= DT_TILE &&
+  // (SDA_DZ_TILES_MIN=<rows> in the environment moves the hand-over between the two forms: diagnostics)
+  static const int min_rows = [] { const char* e = getenv("SDA_DZ_TILES_MIN"); return e ? atoi(e) : DZ_ROWS + 1; }();
+  return (dtype == SDA_BF16 || dtype == SDA_F16) && Bm >= min_rows && Bm % 32 == 0 && Bn >= 1 && row_elems >= DT_TILE &&
          row_elems % DT_TILE == 0 && row_elems / DT_TILE < 0x7fffffffL && 32L * row_elems * 2 < (1L << 32);
 }
 

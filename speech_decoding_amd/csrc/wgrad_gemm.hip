@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
   const E* __restrict__ xg = reinterpret_cast<const E*>(a.x);
   const int s_beg = a.seg_start ? a.seg_start[seg] : 0;
   const int s_end = a.seg_start ? a.seg_start[seg + 1] : a.B;
-  const int nchunk = (a.T + KT - 1) / KT;
+  const int nchunk_plain = (a.T + KT - 1) / KT;
   // Two ways to cut a segment's rows into K-chunks of KT rows:
   //   per sample (the general form; `perm` may reorder samples): chunk it = (sample it / nchunk, rows [ch * KT, ch * KT + KT) of it);
   //     a sample's last chunk is partial (T = 360: 5 x 64 + 40) and takes the per-lane staging path;
@@ -140,8 +140,16 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
   //     segment's very last chunk is partial, every other one takes the scalar-base staging path, and 376 / 360 rows are
   //     contracted per sample instead of 384 / 360.
   const bool flat = (a.flags & SDA_WGRAD_FLAT_ROWS) && !a.perm && s_end > s_beg;
+  // With a sample permutation (per-subject segments: a segment's samples are not neighbours in memory) the same guarantee —
+  // dy is zero on the pad rows around every sample — lets each SAMPLE be contracted as whole chunks: its run of T rows is
+  // extended by `lead` rows of its own leading padding and the rest into the next sample's (T = 360: 16 + 360 + 8 = six
+  // 64-row chunks, none partial: no per-lane staging path, 1 chunk in 6 before).
+  const int pad_need = (KT - a.T % KT) % KT;
+  const bool padded = (a.flags & SDA_WGRAD_FLAT_ROWS) && a.perm && pad_need <= 2 * PAD;
+  const int pad_lead = padded ? (pad_need < PAD ? pad_need : PAD) : 0;
   const long seg_r0 = a.row0 + (long)s_beg * a.sample_rows;                               // first row of the run
   const long seg_r1 = a.row0 + (long)(s_end - 1) * a.sample_rows + a.T;                   // one past its last valid row
+  const int nchunk = padded ? (a.T + pad_need) / KT : nchunk_plain;
   const int total = flat ? (int)((seg_r1 - seg_r0 + KT - 1) / KT) : (s_end - s_beg) * nchunk;
 
   // one K-chunk = KT rows.  DMA pieces are 1 KB, lane-linear in LDS; each lane derives the (row, chunk) its 16 bytes
@@ -165,9 +173,9 @@ __global__ __launch_bounds__(256, (WGeom<E, TILE_M, KS, TN, KM, NS>::LDS > 80 * 
       if (it != 0) { cur_ch = 0; ++cur_si; }
       staged_b = a.perm ? __builtin_amdgcn_readfirstlane(a.perm[s_beg + cur_si]) : (s_beg + cur_si);
     }
-    const int t0 = cur_ch * KT;
+    const int t0 = cur_ch * KT - pad_lead;
     c_row = a.row0 + (long)staged_b * a.sample_rows + t0;
-    c_valid = a.T - t0 < KT ? a.T - t0 : KT;
+    c_valid = padded ? KT : (a.T - t0 < KT ? a.T - t0 : KT);
   };
   auto stage = [&](int it, int buf) {
     describe(it);

@@ -816,7 +816,7 @@ class EncoderEngine:
         def subj_wgrad():
             r = ctx.subj_slices
             slabs = ops.wgrad_gemm(dhs, bufs["h_c"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg,
-                                   nseg=r * d.S)                        # (r*S, 1, D1p, D1p), slice-major
+                                   nseg=r * d.S, flat_rows=self.wgrad_flat_rows)   # (r*S, 1, D1p, D1p), slice-major
             if r > 1:
                 slabs = ops.reduce_slabs(slabs.view(r, -1)).view(d.S, 1, d.D1p, d.D1p)
             return ops.unpack_conv_wgrad(slabs, d.S, d.D1, d.D1, 1, d.D1p, d.D1p)
@@ -829,7 +829,7 @@ class EncoderEngine:
             # neither conv0's data gradient (a 320 -> 320 kernel-3 conv) nor a weight gradient over dx0 is computed.
             if self.skip_x0_gradient:
                 M = ops.wgrad_gemm(dh0, bufs["Xt"], B=B, T=T, KS=3, dil=block_dilations(0)[0], perm=ctx.subj_perm,
-                                   seg_start=ctx.subj_seg, nseg=r * d.S)     # (r*S, 3, D2p, Cp); column C: the folded bias
+                                   seg_start=ctx.subj_seg, nseg=r * d.S, flat_rows=self.wgrad_flat_rows)     # (r*S, 3, D2p, Cp); column C: the folded bias
                 if r > 1:
                     M = ops.reduce_slabs(M.view(r, -1))
                 if w0cat_ready is not None:
@@ -837,7 +837,7 @@ class EncoderEngine:
                 G = ops.param_gemm(W0cat.view(d.D1, 3 * d.D2p), M.view(d.S, 3 * d.D2p, d.Cp)[:, :, : d.C + 1])   # (S, D1, C + 1)
             else:
                 slabs = ops.wgrad_gemm(dhs, bufs["Xt"], B=B, T=T, KS=1, dil=0, perm=ctx.subj_perm, seg_start=ctx.subj_seg,
-                                       nseg=r * d.S)                    # (r*S, 1, D1p, Cp): dL/dW_tot[s], column C = dL/db_tot[s]
+                                       nseg=r * d.S, flat_rows=self.wgrad_flat_rows)   # (r*S, 1, D1p, Cp): dL/dW_tot[s], column C = dL/db_tot[s]
                 if r > 1:
                     slabs = ops.reduce_slabs(slabs.view(r, -1))
                 G = slabs.view(d.S, d.D1p, d.Cp)[:, : d.D1, : d.C + 1]                            # (S, D1, C + 1) view

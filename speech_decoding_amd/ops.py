@@ -638,7 +638,7 @@ def wgrad_gemm(dy, x, *, B, T, KS, dil, perm=None, seg_start=None, nseg=1, alg_d
     a.dy_pitch, a.x_pitch, a.out_pitch = dy.shape[1], x.shape[1], 0
     a.row0, a.sample_rows, a.rows_limit, a.dy_zero_row = L.ROW_PAD, L.rows_tp(T), x.shape[0], 0
     a.co_valid, a.dtype, a.acc_scale = 0, dt_code(x.dtype), None
-    a.flags = L.WGRAD_FLAT_ROWS if (flat_rows and perm is None) else 0
+    a.flags = L.WGRAD_FLAT_ROWS if flat_rows else 0      # (with `perm`: every sample as whole chunks across its own padding)
     if nseg > 1 and seg_start is None:
         raise L.SdaError("wgrad_gemm: nseg > 1 needs seg_start")
     if TIMER is not None and "wgrad_gemm" in TIMER.families:   # events go on the CURRENT stream (the side stream in backward)

@@ -465,6 +465,38 @@ def test_wgrad_per_subject_segments(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,KS,dil", [(360, 3, 1), (360, 3, 16), (100, 3, 4), (104, 1, 0), (130, 3, 2)])
+def test_wgrad_per_subject_segments_on_padded_samples(ops, dtype, T, KS, dil):
+    """SDA_WGRAD_FLAT_ROWS with a sample permutation (round 5): every sample contracted as whole K-chunks across the zero rows
+    around it (T = 360: 16 + 360 + 8; T = 130: needs 62 extra rows, more than the padding holds -> the plain per-sample form).
+    Equal to the plain form up to the fp32 accumulation order (the rows fall into different K-steps): the extra rows are exact
+    zeros in dy."""
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(T + dil)
+    B, Cin, Cout, S = 7, 70, 160, 3
+    x = q(torch.randn(B, Cin, T, generator=g), dtype)
+    dy = q(torch.randn(B, Cout, T, generator=g), dtype)
+    sidx = np.array([2, 0, 2, 2, 0, 2, 0])
+    order = np.argsort(sidx, kind="stable").astype(np.int32)
+    seg = np.searchsorted(sidx[order], np.arange(S + 1)).astype(np.int32)
+    dyt, xt = to_rows(ops, dy, dtype), to_rows(ops, x, dtype)
+    kw = dict(B=B, T=T, KS=KS, dil=dil, perm=torch.from_numpy(order).to(DEV), seg_start=torch.from_numpy(seg).to(DEV), nseg=S)
+    plain = ops.wgrad_gemm(dyt, xt, **kw)
+    padded = ops.wgrad_gemm(dyt, xt, flat_rows=True, **kw)
+    assert float((plain - padded).abs().max()) <= 2e-5 * float(plain.abs().max())
+    ref = torch.zeros(S, KS, Cout, Cin)
+    xp = TF.pad(x, (dil, dil))
+    for b in range(B):
+        for tap in range(KS):
+            off = tap * dil if KS == 3 else 0
+            ref[sidx[b], tap] += dy[b] @ (xp[b][:, off: off + T] if KS == 3 else x[b]).T
+    got = padded[:, :, :Cout, :Cin].cpu()
+    t_ = tol(dtype, 3 * T) if dtype != torch.float32 else dict(rtol=1e-4, atol=2e-4)      # (fp32: ~2 500-term sums of O(1) products)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), **t_)
+    assert float(got[1].abs().max()) == 0.0          # subject absent from the batch
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C,T", [(24, 40), (320, 200)])
 def test_batchnorm_gelu_forward_backward(ops, dtype, C, T):
     from speech_decoding_amd import lib as L

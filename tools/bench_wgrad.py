@@ -29,7 +29,7 @@ for (cin, cout, KS, dil, wgs) in [(320, 320, 3, 4, 256), (320, 320, 3, 4, 512), 
     nseg = 8 * max(1, round(wgs / (8 * ntiles)))
     seg = torch.from_numpy(np.floor(np.linspace(0, B, nseg + 1)).astype(np.int32)).to(dev)
     fl = 2.0 * B * T * KS * cin * cout
-    us = timeit(lambda: ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=None, seg_start=seg, nseg=nseg))
+    us = timeit(lambda: ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=None, seg_start=seg, nseg=nseg, flat_rows=True))
     print(f"wgrad {cin:4d}->{cout:4d} k{KS} tiles {ntiles:3d} nseg {nseg:3d} ({ntiles * nseg:4d} wgs) {us:8.1f} us  {fl / us / 1e6:7.1f} TF", flush=True)
 F = 1024
 for Bm, Bn in [(256, 256), (2048, 256)]:

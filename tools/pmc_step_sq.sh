@@ -3,7 +3,7 @@
 #     bash tools/pmc_step_sq.sh r04      ->  gpurun_out/r04/step_sq_counters.txt  (copy into profiles/ by hand)
 # MFMA utilisation of a kernel = SQ_VALU_MFMA_BUSY_CYCLES / (32 * SQ_BUSY_CYCLES): the first counts matrix-pipe cycles summed
 # over the chip's 1024 SIMDs, the second busy cycles summed over its 32 shader engines (MI355X_MICROARCH.md, cycle constants).
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
