@@ -34,7 +34,7 @@ extern "C" {
                                3: sda_wgrad_args.flags (SDA_WGRAD_FLAT_ROWS), sda_stream_create_cumask / sda_stream_create_priority / sda_stream_destroy, sda_sim_gemm / sda_sim_gemm_ksplit,
                                conv3_flat takes x_pitch == w_pitch only
                                4: sda_fill_zero, sda_gather_samples, sda_clip_merge_rows; SDA_WGRAD_FLAT_ROWS with a sample permutation;
-                                  sda_clip_dz serves more than 256 speech rows (256 x 256 tiles) */
+                                  sda_clip_dz serves more than 256 speech rows (256 x 256 tiles); SDA_CONV_WIDE_TILES */
 #define SDA_ROW_PAD 16
 #define SDA_CH_ALIGN 64
 
@@ -59,6 +59,11 @@ enum { SDA_EPI_GELU = 1,
                                        Cout_p % 160 == 0 or Cout_p % 128 == 0, shared weights, no residual / statistics:
                                        the same tiling (conv1_flat.hip); other shapes ignore the flag.  `stats` then has
                                        sda_conv_stats_rows(...) rows instead of B * n_t_tiles */
+       SDA_CONV_WIDE_TILES = 524288,/* kernel size 1, 16-bit storage, Cout_p % 256 == 0 or % 320 == 0, shared weights, no residual: 256-row x
+                                       256- / 320-channel tiles of the flat row space, eight waves, one persistent workgroup per CU
+                                       (conv1_wide.hip); takes SDA_EPI_GELU (+ y_pre), SDA_EPI_GELU_BWD (`stats` = one row per 256-row
+                                       tile: sda_conv_stats_rows), SDA_EPI_ROW_SUMSQ (Cout_p % 256 == 0).  Any other shape with this
+                                       flag is an error, not a fallback */
        SDA_EPI_GELU_BWD = 65536,    /* kernel size 1 (flat tiles or one tile per workgroup): the conv's output is the gradient entering a GELU whose input u = bn_x ([rows][Cout_p],
                                        same layout as y) the forward kept: y = round(conv) * GELU'(u) (what sda_gelu_backward_colsum
                                        computes from the stored gradient), `stats` rows (sda_conv_stats_rows) = per-unit column

@@ -673,6 +673,7 @@ int launch_conv3_flat(const sda_conv_args& a, hipStream_t st) {
 // (one per 128-row tile of a sample), the flat-tile kernel one per 128-row unit of the flat row space
 extern "C" int sda_conv_stats_rows(int B, int T, int KS, int Cout_p, int flags) {
   if ((flags & SDA_CONV_FLAT_TILES) && KS == 3 && Cout_p % sda::F_CO == 0) return sda::conv3_flat_stat_rows(B, T);
+  if ((flags & SDA_CONV_WIDE_TILES) && KS == 1 && (flags & SDA_EPI_GELU_BWD)) return sda::conv1_wide_stat_rows(B, T);   // conv1_wide: one row per 256-row tile
   if ((flags & SDA_CONV_FLAT_TILES) && KS == 1 && (flags & SDA_EPI_GELU_BWD)) return sda::conv3_flat_stat_rows(B, T);   // conv1_flat: same units
   return B * ((T + sda::TILE_T - 1) / sda::TILE_T);
 }

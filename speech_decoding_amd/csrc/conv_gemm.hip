@@ -683,9 +683,14 @@ static int dispatch_conv(const sda_conv_args& a, hipStream_t st) {
     if (!conv3_flat_supports(a)) { set_error("conv_gemm: SDA_CONV_FLAT_TILES needs a plain row-layout kernel-3 convolution"); return -1; }
     return launch_conv3_flat(a, st);
   }
+  if ((a.flags & SDA_CONV_WIDE_TILES) && a.KS == 1) {
+    // (an error, not a fallback: the statistics rows a caller sized with sda_conv_stats_rows must be the rows written)
+    if (!conv1_wide_supports(a)) { set_error("conv_gemm: SDA_CONV_WIDE_TILES needs a plain row-layout kernel-1 convolution, 16-bit storage, Cout_p %% 256 == 0 or %% 320 == 0"); return -1; }
+    return launch_conv1_wide(a, st);
+  }
   if ((a.flags & SDA_CONV_FLAT_TILES) && a.KS == 1 && conv1_flat_supports(a)) return launch_conv1_flat(a, st);
   if (a.flags & SDA_EPI_ROW_SUMSQ) {
-    set_error("conv_gemm: SDA_EPI_ROW_SUMSQ needs SDA_CONV_FLAT_TILES and a plain row-layout kernel-1 convolution with Cout_p % 128 == 0");
+    set_error("conv_gemm: SDA_EPI_ROW_SUMSQ needs SDA_CONV_FLAT_TILES (or SDA_CONV_WIDE_TILES) and a plain row-layout kernel-1 convolution with Cout_p % 128 == 0");
     return -1;
   }
   if ((a.flags & SDA_EPI_GELU_BWD) && (!a.bn_x || !a.stats || a.bias || a.y_pre || a.res || a.partial || a.KS != 1 ||

@@ -26,4 +26,9 @@ int conv3_flat_stat_rows(int B, int T);
 int launch_conv1_flat(const sda_conv_args& a, hipStream_t st);
 bool conv1_flat_supports(const sda_conv_args& a);
 
+// conv1_wide.hip
+int launch_conv1_wide(const sda_conv_args& a, hipStream_t st);
+bool conv1_wide_supports(const sda_conv_args& a);
+int conv1_wide_stat_rows(int B, int T);
+
 }  // namespace sda

@@ -150,6 +150,15 @@ class EncoderEngine:
         #  is worth 0.10 ms — 6.77-6.87 vs 6.91-6.92, three alternations — and the forward pair nothing: 6.80-6.87 with both)
         self.flat_1x1_forward = False
         self.flat_1x1_backward = True
+        # round 5: conv1_wide.hip's 256-row x 256 / 320-channel tiles (eight waves, one persistent workgroup per CU, the next
+        # tile's K-steps requested before the epilogue of the current one; 16-bit storage, widths that are multiples of 256 or
+        # 320).  Alone at config 2 (tools/probes/bench_1x1_wide.py, us, tile / flat / wide): conv_final2 forward 246 / 253 / 216,
+        # conv_final1 forward 105 / 106 / 106, conv_final2's data gradient 211 / 180 / 180, conv_final1's 60 / 46 / 58.  In the
+        # step: conv_final2 forward on it (nothing co-runs in forward; -0.03 ms, inside the noise of an alternation); the data
+        # gradients on it +0.2 ms (one 160 KB workgroup per CU: the weight-gradient GEMMs wait instead of running beside them)
+        self.wide_1x1_forward = True         # conv_final2's forward (widths that are multiples of 256)
+        self.wide_1x1_forward_all = False    # ... conv_final1's as well (320-channel tiles: equal to the tile kernel)
+        self.wide_1x1_backward = False
         self.flat_1x1_options = 0            # extra conv1_flat flags (1024 = staggered tile order, 32768 = one workgroup per CU)
         # CU partition for backward (experiment, default off): k > 0 gives the data-gradient chain (the stream backward() is
         # called on hands over to a CU-masked stream) k of the 8 XCDs and the weight-gradient stream the other 8 - k, instead
@@ -473,16 +482,19 @@ class EncoderEngine:
         # ---- two 1x1 projections with GELU (models.py:194-195)
         u1, g1 = rows("u1", d.F1p), rows("g1", d.F1p)
         f_flags = (L.CONV_FLAT_TILES | self.flat_1x1_options) if self.flat_1x1_forward else 0
+        wide_ok = lambda cp: dt != torch.float32 and (cp % 256 == 0 or cp % 320 == 0)      # noqa: E731
+        f1_flags = L.CONV_WIDE_TILES if (self.wide_1x1_forward_all and wide_ok(d.F1p)) else f_flags
+        f2_wide = bool(self.wide_1x1_forward and dt != torch.float32 and d.Fp % 256 == 0)
         ops.conv_gemm(x, pk["f1w"], g1, B=B, T=T, KS=1, dil=0, bias=pk["f1b"], y_pre=u1 if need_grad else None,
-                      gelu=True, alg_dims=(d.D2, d.F1), flags=f_flags)
+                      gelu=True, alg_dims=(d.D2, d.F1), flags=f1_flags)
         # Z is handed to the caller: a FRESH buffer per forward (the reference returns a new tensor each call), so
         # embeddings kept across forwards stay valid; everything else lives in the reused workspace
         u2, Zt = rows("u2", d.Fp), ops.new_rows_uninit(B, T, d.Fp, dt, dev)
         # ||Z_b||^2 for the loss comes out of the epilogue's sums: no separate pass over Z (loss.py:65)
-        if f_flags and d.Fp % 128 == 0:
+        if f2_wide or (f_flags and d.Fp % 128 == 0):
             zparts = torch.empty((B * L.rows_tp(T), d.Fp // 128), dtype=torch.float32, device=dev)
             ops.conv_gemm(g1, pk["f2w"], Zt, B=B, T=T, KS=1, dil=0, bias=pk["f2b"], y_pre=u2 if need_grad else None,
-                          gelu=True, row_sumsq=zparts, alg_dims=(d.F1, d.F), flags=f_flags)
+                          gelu=True, row_sumsq=zparts, alg_dims=(d.F1, d.F), flags=L.CONV_WIDE_TILES if f2_wide else f_flags)
             ops.ROW_NORMS.put(Zt, ops.rows_sumsq_from_row_parts(zparts, B, T))
         else:
             zstats = torch.empty((B * ops.n_t_tiles(T), 2, d.Fp), dtype=torch.float32, device=dev)
@@ -716,12 +728,17 @@ class EncoderEngine:
         du2 = tmp("du2", d.Fp)
         grads["f2b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u2"], dZt, du2, width=d.Fp, then=lambda cs: bias_grad(cs, d.F))
         b1_flags = (L.CONV_FLAT_TILES | self.flat_1x1_options) if self.flat_1x1_backward else 0
+        wide_ok = lambda cp: dt != torch.float32 and (cp % 256 == 0 or cp % 320 == 0)      # noqa: E731
+        b2_flags = b1_flags                   # conv_final2's data gradient (width F1p) / conv_final1's (width D2p)
+        if self.wide_1x1_backward and wide_ok(d.F1p):
+            b2_flags = L.CONV_WIDE_TILES
+        b1w_flags = L.CONV_WIDE_TILES if (self.wide_1x1_backward and wide_ok(d.D2p)) else b1_flags
         du1 = tmp("du1", d.F1p)
-        if self.fuse_gelu_backward_1x1 or (b1_flags and (d.F1p % 160 == 0 or d.F1p % 128 == 0)):
+        if self.fuse_gelu_backward_1x1 or (b2_flags & L.CONV_WIDE_TILES) or (b1_flags and (d.F1p % 160 == 0 or d.F1p % 128 == 0)):
             # conv_final2's data gradient with conv_final1's GELU backward in its epilogue: du1 directly, plus per-unit column sums
-            gst = torch.empty((ops.conv_stats_rows(B, T, 1, d.F1p, b1_flags | L.EPI_GELU_BWD), 2, d.F1p), dtype=torch.float32, device=dev)
+            gst = torch.empty((ops.conv_stats_rows(B, T, 1, d.F1p, b2_flags | L.EPI_GELU_BWD), 2, d.F1p), dtype=torch.float32, device=dev)
             ops.conv_gemm(du2, ctx.packed_T["f2w"], du1, B=B, T=T, KS=1, dil=0, gelu_bwd_u=bufs["u1"], stats=gst,
-                          alg_dims=(d.F, d.F1), flags=b1_flags)
+                          alg_dims=(d.F, d.F1), flags=b2_flags)
             grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
             grads["f1b"] = on_side(lambda: bias_grad(ops.reduce_stats(gst)[:d.F1p], d.F1))
         else:
@@ -737,8 +754,8 @@ class EncoderEngine:
             glu_pending = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dc2.4", 2 * d.D2p), 1, 0, glu_bwd=(bufs["x5"], bufs["b4.g"]))
             dx = None
         else:
-            if b1_flags:
-                dx = ops.conv_gemm(du1, ctx.packed_T["f1w"], tmp("dxA", d.D2p), B=B, T=T, KS=1, dil=0, alg_dims=(d.F1, d.D2), flags=b1_flags)
+            if b1w_flags:
+                dx = ops.conv_gemm(du1, ctx.packed_T["f1w"], tmp("dxA", d.D2p), B=B, T=T, KS=1, dil=0, alg_dims=(d.F1, d.D2), flags=b1w_flags)
             else:
                 dx, _ = dgrad(du1, "f1w", P["f1w"], d.F1p, d.D2p, tmp("dxA", d.D2p), 1, 0)
         grads["f1w"] = wgrad(du1, bufs["x5"], 1, 0, d.F1, d.D2)

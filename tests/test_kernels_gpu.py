@@ -313,6 +313,84 @@ def test_conv1_flat_row_sumsq_epilogue(ops, dtype, cin, cout, T, B):
     np.testing.assert_allclose(norms.cpu().double().numpy(), ref.numpy(), rtol=2e-6)
 
 
+# conv1_wide.hip (round 5, SDA_CONV_WIDE_TILES): the 1 x 1 convs on 256-row x 256 / 320-channel tiles, eight waves, persistent
+# workgroups — against the tile-per-workgroup kernel (same products, same K order: bit-equal) and torch
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,T,B", [(320, 640, 360, 5), (640, 1024, 129, 3), (1024, 640, 200, 3), (640, 320, 77, 4),
+                                          (64, 256, 50, 9), (96, 512, 1, 9), (320, 640, 360, 64)])
+def test_conv1_wide_tiles_equal_tile_kernel(ops, dtype, cin, cout, T, B):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(21)
+    Cip, Cop = L.pad_channels(cin), L.pad_channels(cout)
+    x = q(torch.randn(B, cin, T, generator=g), dtype)
+    w = q(torch.randn(cout, cin, 1, generator=g) / math.sqrt(cin), dtype)
+    bias = ops.pack_vector(torch.randn(cout, generator=g).to(DEV), Cop)
+    xb = to_rows(ops, x, dtype)
+    wp = ops.pack_conv_weight(w.to(DEV), Cop, Cip, dtype)
+    for kw in (dict(), dict(bias=bias, gelu=True, with_pre=True), dict(bias=bias)):
+        outs = []
+        for flags in (0, L.CONV_WIDE_TILES):
+            kw2 = dict(kw)
+            y, pre = ops.new_rows(B, T, Cop, dtype, DEV), ops.new_rows(B, T, Cop, dtype, DEV)
+            if kw2.pop("with_pre", False):
+                kw2["y_pre"] = pre
+            ops.conv_gemm(xb, wp, y, B=B, T=T, KS=1, dil=0, flags=flags, **kw2)
+            outs.append((y, pre))
+        assert torch.equal(outs[0][0], outs[1][0])        # (pad rows and the slack behind the last sample included: never written)
+        assert torch.equal(outs[0][1], outs[1][1])
+    ref = TF.conv1d(x, w)
+    np.testing.assert_allclose(from_rows(ops, ops.conv_gemm(xb, wp, ops.new_rows(B, T, Cop, dtype, DEV), B=B, T=T, KS=1, dil=0,
+                                                            flags=L.CONV_WIDE_TILES), B, cout, T).numpy(), ref.numpy(), **tol(dtype, cin))
+    # a width that is neither a multiple of 256 nor of 320 is refused, not silently served by another kernel
+    if cout == 640:
+        bad = ops.pack_conv_weight(q(torch.randn(128, cin, 1, generator=g), dtype).to(DEV), 128, Cip, dtype)
+        with pytest.raises(L.SdaError):
+            ops.conv_gemm(xb, bad, ops.new_rows(B, T, 128, dtype, DEV), B=B, T=T, KS=1, dil=0, flags=L.CONV_WIDE_TILES)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,T,B", [(1024, 640, 360, 4), (128, 256, 77, 3), (64, 320, 130, 6), (256, 512, 360, 20)])
+def test_conv1_wide_gelu_backward_epilogue(ops, dtype, cin, cout, T, B):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(22)
+    Cip, Cop = L.pad_channels(cin), L.pad_channels(cout)
+    xb = to_rows(ops, q(torch.randn(B, cin, T, generator=g), dtype), dtype)
+    wp = ops.pack_conv_weight(q(torch.randn(cout, cin, 1, generator=g) / math.sqrt(cin), dtype).to(DEV), Cop, Cip, dtype)
+    ub = to_rows(ops, q(torch.randn(B, cout, T, generator=g), dtype), dtype)
+    dg = ops.conv_gemm(xb, wp, ops.new_rows(B, T, Cop, dtype, DEV), B=B, T=T, KS=1, dil=0)
+    du_ref = ops.new_rows(B, T, Cop, dtype, DEV)
+    cs_ref = ops.gelu_backward_colsum(ub, dg, du_ref, B, T, ops.reduce_scratch(Cop, DEV))
+    du = ops.new_rows(B, T, Cop, dtype, DEV)
+    nrows = ops.conv_stats_rows(B, T, 1, Cop, L.CONV_WIDE_TILES | L.EPI_GELU_BWD)
+    assert nrows == (B * L.rows_tp(T) + 255) // 256
+    st = torch.full((nrows, 2, Cop), float("nan"), device=DEV)
+    ops.conv_gemm(xb, wp, du, B=B, T=T, KS=1, dil=0, flags=L.CONV_WIDE_TILES, gelu_bwd_u=ub, stats=st)
+    assert torch.equal(du, du_ref)
+    assert bool(torch.isfinite(st).all()) and float(st[:, 1].abs().max()) == 0.0
+    t = tol(dtype, B * T)
+    np.testing.assert_allclose(st[:, 0].double().sum(0).cpu().numpy(), cs_ref.double().cpu().numpy(), rtol=1e-4, atol=t["atol"] * 1e-2 + 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,T,B", [(640, 1024, 360, 3), (64, 256, 50, 5), (128, 512, 129, 2)])
+def test_conv1_wide_row_sumsq_epilogue(ops, dtype, cin, cout, T, B):
+    from speech_decoding_amd import lib as L
+    g = torch.Generator().manual_seed(23)
+    Cip, Cop = L.pad_channels(cin), L.pad_channels(cout)
+    xb = to_rows(ops, q(torch.randn(B, cin, T, generator=g), dtype), dtype)
+    wp = ops.pack_conv_weight(q(torch.randn(cout, cin, 1, generator=g) / math.sqrt(cin), dtype).to(DEV), Cop, Cip, dtype)
+    bias = ops.pack_vector(torch.randn(cout, generator=g).to(DEV), Cop)
+    y0, pre0 = ops.new_rows(B, T, Cop, dtype, DEV), ops.new_rows(B, T, Cop, dtype, DEV)
+    ops.conv_gemm(xb, wp, y0, B=B, T=T, KS=1, dil=0, bias=bias, gelu=True, y_pre=pre0)
+    parts = torch.full((L.rows_alloc(B, T), Cop // 128), float("nan"), device=DEV)
+    y, pre = ops.new_rows(B, T, Cop, dtype, DEV), ops.new_rows(B, T, Cop, dtype, DEV)
+    ops.conv_gemm(xb, wp, y, B=B, T=T, KS=1, dil=0, bias=bias, gelu=True, y_pre=pre, flags=L.CONV_WIDE_TILES, row_sumsq=parts)
+    assert torch.equal(y, y0) and torch.equal(pre, pre0)
+    norms = ops.rows_sumsq_from_row_parts(parts, B, T)
+    ref = from_rows(ops, y, B, cout, T).double().pow(2).sum(dim=(1, 2))
+    np.testing.assert_allclose(norms.cpu().double().numpy(), ref.numpy(), rtol=2e-6)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,dil,T,glu", [(40, 48, 2, 70, False), (320, 320, 4, 200, False),
                                                 (64, 48, 2, 90, True), (320, 640, 2, 140, True)])
