@@ -352,7 +352,10 @@ int sda_clip_grad(const float* logits, const float* row_lse, const float* col_ls
  *     out[j][k] = out_scale[0] * (cscale[j] * sum_{i < Bm} G[i][j] * Y[i][k] - rscale[j] * Z[j][k]),   j < Bn, k < row_elems
  * G [Bm][g_pitch], Y [Bm][row_elems], Z and out [Bn][row_elems] of `dtype` (16-bit types only), cscale / rscale fp32 [Bn]
  * (cscale may be NULL = 1), out_scale a device scalar or NULL.  Same result as sda_wgrad_gemm's typed-output mode, which
- * serves what this one does not: sda_clip_dz_supported() says whether (Bm <= 256, row_elems % 64 == 0, bf16 / fp16) holds. */
+ * serves what this one does not: sda_clip_dz_supported() says whether a shape is served — bf16 / fp16 and either
+ * Bm <= 256 with row_elems % 64 == 0 (the coefficient matrix in registers) or, ABI 4, Bm >= 256 with Bm % 32 == 0,
+ * row_elems % 256 == 0 and g_pitch % 8 == 0 (256 x 256 tiles: any number of speech rows — a rank's block under data
+ * parallelism contracts over the GLOBAL batch, loss.py:68 with x all-gathered). */
 int sda_clip_dz_supported(int Bm, int Bn, long row_elems, int dtype);
 int sda_clip_dz(const void* G, long g_pitch, const void* Y, const void* Z, void* out, const float* cscale, const float* rscale,
                 const float* out_scale, int Bm, int Bn, long row_elems, int dtype, void* stream);

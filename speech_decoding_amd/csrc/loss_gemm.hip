@@ -394,7 +394,7 @@ int launch_dz_tiles(const void* G, long g_pitch, const void* Y, const void* Z, v
 // shapes of the tiled form: whole 32-row K-steps, whole 256-element column tiles, per-lane offsets inside 32 bits
 static bool dz_tiles_ok(int Bm, int Bn, long row_elems, int dtype) {
   // (SDA_DZ_TILES_MIN=<rows> in the environment moves the hand-over between the two forms: diagnostics)
-  static const int min_rows = [] { const char* e = getenv("SDA_DZ_TILES_MIN"); return e ? atoi(e) : DZ_ROWS + 1; }();
+  static const int min_rows = [] { const char* e = getenv("SDA_DZ_TILES_MIN"); return e ? atoi(e) : DZ_ROWS; }();
   return (dtype == SDA_BF16 || dtype == SDA_F16) && Bm >= min_rows && Bm % 32 == 0 && Bn >= 1 && row_elems >= DT_TILE &&
          row_elems % DT_TILE == 0 && row_elems / DT_TILE < 0x7fffffffL && 32L * row_elems * 2 < (1L << 32);
 }
