@@ -67,3 +67,30 @@ def test_bench_single_gpu_line_carries_the_contract_fields():
     assert line["n_gpus"] == 1 and line["dtype"] == "bf16" and line["vs_baseline"] is None
     r = line["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
+
+
+def test_bench_emulated_world_config_and_feed_legs():
+    """Round-5 modes: `--emulate-world` (ONE JSON line although RCCL prints a banner on stdout; global batch, workload text and
+    collective brackets of the emulated world), `--config 4` (per-GPU shape of configs[3]) and the `with_feed` leg."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SDA_DP_SINGLE_RANK"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--timer-steps", "1", "--no-host-sync-leg"]
+    out = subprocess.run(base + ["--batch", "32", "--emulate-world", "4", "--coll-timer-steps", "1"], env=env, capture_output=True,
+                         text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.count("\n") == 1, out.stdout[-1000:]            # exactly one line on stdout: the JSON
+    (line,) = _json_lines(out.stdout)
+    assert line["n_gpus"] == 1 and line["config"]["global_batch"] == 128 and "emulating dp4" in line["config"]["parallelism"]
+    assert "PER-RANK step of a 4-rank job" in line["config"]["workload"] and "cpu_baseline" not in line and "with_feed" not in line
+    coll = line["collectives_us_per_step"]
+    assert sum(v["calls_per_step"] for k, v in coll.items() if k.startswith("all_reduce 2560 B")) >= 20
+    assert line["roofline"]["traffic"] is None
+    out = subprocess.run(base + ["--config", "4", "--batch", "32"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    (line,) = _json_lines(out.stdout)
+    assert "60 ch x 360" in line["config"]["workload"] and "configs[3]" in line["config"]["workload"] and "cpu_baseline" not in line
+    out = subprocess.run(base + ["--batch", "32", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    (line,) = _json_lines(out.stdout)
+    assert line["with_feed"]["value"] > 0 and line["with_feed"]["host_enqueue_ms_per_step"] > 0

@@ -59,6 +59,38 @@ WORKER = textwrap.dedent("""
                 continue                                        # null gradients: rounding noise on both sides
             assert float((g1[k] - g0[k]).abs().max()) <= 2e-3 * float(g0[k].abs().max()) + 1e-7, k
         assert side_group("grads", active_group()) is not active_group()        # communicators of their own exist
+    # ---- bench.py --emulate-world: one rank behaving as rank 0 of W (distributed.emulate_world): the loss sees W * B speech
+    # rows — its own through the real all-gather, (W - 1) * B resident stand-ins — and must equal the engine's block form on
+    # exactly those rows (the tiled embedding gradient included: 288 speech rows x 96 columns, bf16)
+    from speech_decoding_amd import CLIPLoss, engine as E, lib as L, ops
+    from speech_decoding_amd import loss as sda_loss
+    from speech_decoding_amd.distributed import emulate_world
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    B, W, F, T = 96, 3, 64, 44
+    g = torch.Generator().manual_seed(31)
+    Yl, Zl = torch.randn(B, F, T, generator=g).to(DEV), torch.randn(B, F, T, generator=g).to(DEV)
+    emulate_world(W)
+    lossf = CLIPLoss(A(reduction="mean", init_temperature=5.1)).to(DEV)
+    Zt = sda_loss.as_rows(Zl, B, F, T, torch.bfloat16, "Z")
+    Zv = ops.rows_view(Zt, B, F, T).requires_grad_(True)
+    lossf.prefetch(Yl, torch.bfloat16)
+    loss = lossf(Yl, Zv)
+    loss.backward()
+    rows, nsq = next(iter(lossf._state.emulated.values()))
+    Tp = L.rows_tp(T)
+    Yall = ops.new_rows(W * B, T, F, torch.bfloat16, DEV)
+    ops.pack_rows(Yl, Yall)
+    Yall[B * Tp: W * B * Tp].copy_(rows)
+    share, logits, cnt, cctx = E.clip_forward(Yall, Zt, lossf.temp.detach(), Bm=W * B, Bn=B, T=T, col0=0, B_global=W * B)
+    dZt = ops.new_rows(B, T, F, torch.bfloat16, DEV)
+    E.clip_backward(cctx, dZt, torch.ones(1, device=DEV))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(share)) <= 1e-6 * max(1.0, abs(float(share))), (float(loss), float(share))
+    assert torch.equal(lossf.last_logits, logits) and tuple(logits.shape) == (W * B, B)
+    assert torch.equal(Zv.grad, ops.rows_view(dZt, B, F, T))
+    assert abs(float(lossf.temp.grad) - float(cctx.dtemp)) <= 1e-6 * max(1.0, abs(float(cctx.dtemp)))
+    emulate_world(1)
     dist.barrier()
     dist.destroy_process_group()
     print("rccl single-rank ok")
