@@ -396,7 +396,10 @@ def main():
     if a.config == 2 and world == 1 and emu == 1 and not a.no_feed_leg:
         from speech_decoding_amd.data import ShardedRandomSampler, synthetic_resident_dataset
         n_feed = max(3, min(20, a.steps))
-        feed, train_idx, _ = synthetic_resident_dataset(cfg, dev, n_segments=4 * B, seed=1234)
+        # (as in the real dataset every task is heard by many subjects: ceil(S / 4) recordings per task, so that a batch spans
+        # all S subjects like the pool's uniformly drawn indices — with two recordings per task only 8 of the 27 subjects
+        # ever occur and the per-subject weight gradient of the SubjectBlock runs on a third of its workgroups)
+        feed, train_idx, _ = synthetic_resident_dataset(cfg, dev, n_segments=4 * B, seed=1234, recs_per_task=int(os.environ.get("SDA_FEED_RECS", -(-S // 4))))
         feed.pack_embeddings(enc.compute_dtype)              # the embedding table resident in row layout: Y arrives packed
         sampler = ShardedRandomSampler(len(train_idx), B, n_feed + 5, rank, world, seed=4321)
         # The feed's stream has LOW priority (the step's chain is the critical path: a freed CU slot goes to it first) and starts
@@ -414,6 +417,11 @@ def main():
             idx = next(it, None)
             if idx is None:
                 return None
+            if feed_at == "inline":                          # on the step's own stream, in program order (diagnostic)
+                Xf, Yf, sf = feed.batch(train_idx[idx.numpy()])
+                ev = torch.cuda.Event()
+                ev.record(main_stream)
+                return Xf, Yf, sf, ev
             if behind_main:
                 gate = torch.cuda.Event()
                 gate.record(main_stream)

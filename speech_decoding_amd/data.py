@@ -154,9 +154,11 @@ class ResidentSegmentFeed:
             yield self.batch(i if index_map is None else np.asarray(index_map)[i])
 
 
-def synthetic_resident_dataset(args, device, *, n_segments: int, n_tasks: int = 4, seed: int = 1234) -> Tuple[ResidentSegmentFeed, np.ndarray, np.ndarray]:
+def synthetic_resident_dataset(args, device, *, n_segments: int, n_tasks: int = 4, seed: int = 1234,
+                               recs_per_task: int = 2) -> Tuple[ResidentSegmentFeed, np.ndarray, np.ndarray]:
     """Seeded stand-in with the STRUCTURE of Gwilliams2022 (27 subjects x up to 2 sessions x 4 tasks of ~100 k samples are
-    not needed to exercise the path): `n_tasks` tasks, two recordings per task from different subjects, segments laid out
+    not needed to exercise the path): `n_tasks` tasks, `recs_per_task` recordings per task from different subjects (the real
+    dataset has every subject hear every task: pass ceil(S / n_tasks) to see all S subjects in a batch), segments laid out
     back to back with an overlap; the speech embedding of a segment is a fixed linear read-out of the raw window of the
     task's FIRST recording plus noise, so retrieval is learnable.  Returns (feed, train indices, test indices)."""
     C = int(args.get("num_channels", 208 if args.dataset == "Gwilliams2022" else 60))
@@ -172,10 +174,10 @@ def synthetic_resident_dataset(args, device, *, n_segments: int, n_tasks: int = 
     recordings, rec_subject, rec_task, onsets = [], [], [], []
     for t in range(n_tasks):
         base = torch.randn(C, Lr, generator=g)
-        for k in range(2):
+        for k in range(recs_per_task):
             drift = torch.linspace(0, float(k + 1), Lr)[None, :] * torch.randn(C, 1, generator=g)     # what the collate removes
             recordings.append(((base + 0.3 * torch.randn(C, Lr, generator=g)) * (2.0 + k) + drift).to(device))
-            rec_subject.append((2 * t + k) % S)
+            rec_subject.append((recs_per_task * t + k) % S)
             rec_task.append(t)
             onsets.append(np.arange(per_task, dtype=np.int64) * hop + 7 * k)
     seg_task = np.repeat(np.arange(n_tasks), per_task)[:n_segments]
@@ -183,7 +185,7 @@ def synthetic_resident_dataset(args, device, *, n_segments: int, n_tasks: int = 
     P = torch.randn(F, C, generator=g) / np.sqrt(C)
     Y = torch.empty((n_segments, F, T))
     for i in range(n_segments):
-        r0 = 2 * int(seg_task[i])
+        r0 = recs_per_task * int(seg_task[i])
         o = int(onsets[r0][seg_in_task[i]])
         w = recordings[r0][:, o: o + T].cpu()
         w = (w - w[:, :nb].mean(dim=1, keepdim=True)) / (2.0 * 1.35)
