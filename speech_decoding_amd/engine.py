@@ -109,6 +109,9 @@ class EncoderEngine:
                                              # times: 68.6 -> 67.3 us per 320 -> 320 conv with the priority hand-over, round 4),
                                              # 64 = no priority hand-over between the two (diagnostic)
         self.fuse_glu_forward = True         # F.glu in conv2's epilogue (flat-tile kernel, D2p % 80 == 0): no [value | gate] buffer
+        self.bias_sums_at_end = False        # ... all of them at the END of backward, on the weight-gradient stream (round 5: seven
+                                             # ~10 us launches leave the main chain — and lengthen the serial tail the optimiser
+                                             # waits for: 6.72-6.75 against 6.64-6.68 ms, three alternations; off)
         self.bias_sums_on_side = False       # final reduction of the bias-gradient column sums on the weight-gradient stream
                                              # (round 3: on; re-measured in round 4 against the same library, three alternations on
                                              # one box: 7.15-7.20 ms on, 7.09-7.14 ms off — the short reductions delay the
@@ -719,17 +722,35 @@ class EncoderEngine:
         # ---- final projections
         # the last stage of a bias gradient (partial rows -> column sums) feeds nothing on the main stream: it goes to the
         # weight-gradient stream, each launch with partial rows of its own
-        def colsum_on_side(fn, *args, width, then=None):
+        deferred_sums = []                    # (gradient name, finish closure): final reductions postponed to the end of backward
+
+        def colsum_on_side(fn, *args, width, then=None, name=None):
             """Column sums of fn's output; `then` (the bias-gradient un-packing, where it needs a kernel) runs on the SAME
-            stream as the sums' final reduction, right behind it: on the main stream it would read them before they exist."""
+            stream as the sums' final reduction, right behind it: on the main stream it would read them before they exist.
+            bias_sums_at_end: the partial rows are kept and the final reduction of every bias gradient runs once, on the
+            weight-gradient stream behind its last GEMM — seven ~10 us launches leave the main chain (nothing on it reads a bias
+            gradient); not under overlapped gradient all-reduces, which want each layer group's gradients as they appear."""
+            if name is not None and side is not None and self.bias_sums_at_end and not overlap:
+                finish = fn(*args, B, T, ops.reduce_scratch(width, dev), defer=True)
+                deferred_sums.append((name, (lambda: then(finish())) if then is not None else finish))
+                return None
             if side is None or not self.bias_sums_on_side:
                 cs = fn(*args, B, T, scratch)
                 return then(cs) if then is not None else cs
             finish = fn(*args, B, T, ops.reduce_scratch(width, dev), defer=True)
             return on_side((lambda: then(finish())) if then is not None else finish)
 
+        def finish_deferred_sums():
+            if not deferred_sums:
+                return
+            def run():
+                return [fin() for _, fin in deferred_sums]
+            outs = on_side(run)
+            for (nm, _), g_ in zip(deferred_sums, outs):
+                grads[nm] = g_
+
         du2 = tmp("du2", d.Fp)
-        grads["f2b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u2"], dZt, du2, width=d.Fp, then=lambda cs: bias_grad(cs, d.F))
+        grads["f2b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u2"], dZt, du2, width=d.Fp, then=lambda cs: bias_grad(cs, d.F), name="f2b")
         b1_flags = (L.CONV_FLAT_TILES | self.flat_1x1_options) if self.flat_1x1_backward else 0
         wide_ok = lambda cp: dt != torch.float32 and (cp % 256 == 0 or cp % 320 == 0)      # noqa: E731
         b2_flags = b1_flags                   # conv_final2's data gradient (width F1p) / conv_final1's (width D2p)
@@ -747,7 +768,7 @@ class EncoderEngine:
         else:
             dg1, _ = dgrad(du2, "f2w", P["f2w"], d.Fp, d.F1p, tmp("dg1", d.F1p), 1, 0)
             grads["f2w"] = wgrad(du2, bufs["g1"], 1, 0, d.F, d.F1)
-            grads["f1b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u1"], dg1, du1, width=d.F1p, then=lambda cs: bias_grad(cs, d.F1))
+            grads["f1b"] = colsum_on_side(ops.gelu_backward_colsum, bufs["u1"], dg1, du1, width=d.F1p, then=lambda cs: bias_grad(cs, d.F1), name="f1b")
         # Where the forward kept (out, gate) of every F.glu, the conv that produces the gradient entering a block's GLU (this
         # 1x1 data gradient for block 4, conv0's data gradient of block k + 1 for block k) applies the GLU backward in its
         # epilogue: `glu_pending` = (dc2, per-tile column sums) for the block about to be processed, and dx is never stored
@@ -782,7 +803,7 @@ class EncoderEngine:
                 dc2 = tmp(f"dc2.{k}", 2 * d.D2p)      # per-layer buffers: a side-stream wgrad may still read them
                 if ctx.glu_fused:
                     grads[f"b{k}.c2b"] = colsum_on_side(ops.glu_backward_colsum_og, bufs[f"x{k + 1}"], bufs[f"b{k}.g"], dx, dc2,
-                                                        width=2 * d.D2p, then=c2b)
+                                                        width=2 * d.D2p, then=c2b, name=f"b{k}.c2b")
                 else:
                     grads[f"b{k}.c2b"] = c2b(ops.glu_backward_colsum(bufs[f"b{k}.c2"], dx, dc2, B, T, scratch))
             da1, tstats = dgrad(dc2, f"b{k}.c2w", P[f"b{k}.c2w"], 2 * d.D2p, d.D2p, tmp("da", d.D2p), 3, dil[2],
@@ -875,6 +896,7 @@ class EncoderEngine:
             grads["z"] = ops.sa_weights_backward(dWd, ctx.W_sa, ctx.mask, P["cosT"], P["sinT"], P["z"].shape[1],
                                                  bwd_table=P.get("sa_tab_b"))
             flush(["subj_w", "sb_w", "sb_b", "z"])
+            finish_deferred_sums()
             join_side()
             for work in pending:
                 work.wait()
@@ -891,6 +913,7 @@ class EncoderEngine:
         grads["z"] = ops.sa_weights_backward(dWd, ctx.W_sa, ctx.mask, P["cosT"], P["sinT"], P["z"].shape[1],
                                              bwd_table=P.get("sa_tab_b"))
         flush(["subj_w", "sb_w", "sb_b", "z"])
+        finish_deferred_sums()
         join_side()
         for work in pending:
             work.wait()                       # makes the current stream wait for RCCL's; no host sync
