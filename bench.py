@@ -544,6 +544,8 @@ def main():
         from speech_decoding_amd.distributed import shutdown
         lossf.drain()                # the speech rows gathered one batch ahead that no step will consume
         shutdown()
+    torch.cuda.synchronize()
+    ops.stream_destroy_all()         # streams made through the C ABI (the feed leg's low-priority one): nothing is queued any more
 
 
 if __name__ == "__main__":

@@ -31,19 +31,32 @@ def _st():
 
 def stream_create_cumask(words) -> int:
     """A HIP stream restricted to the CUs set in `words` (32 CUs per word); returns the hipStream_t as an integer for
-    torch.cuda.ExternalStream.  Created in this process; never destroyed (a handful per run)."""
+    torch.cuda.ExternalStream.  Created in this process; kept in _CREATED_STREAMS until stream_destroy_all()."""
     arr = (C.c_uint32 * len(words))(*[int(w) & 0xFFFFFFFF for w in words])
     out = C.c_void_p()
     L.check(L.load().sda_stream_create_cumask(arr, len(words), C.byref(out)), "stream_create_cumask")
+    _CREATED_STREAMS.append(int(out.value))
     return int(out.value)
 
 
 def stream_create_priority(priority: int) -> int:
     """A non-blocking HIP stream of `priority` (-1 high, 0 normal, 1 LOW: the last is below anything torch's stream pool
-    hands out); returns the hipStream_t as an integer for torch.cuda.ExternalStream.  Never destroyed (one per device)."""
+    hands out); returns the hipStream_t as an integer for torch.cuda.ExternalStream (destroyed by stream_destroy_all())."""
     out = C.c_void_p()
     L.check(L.load().sda_stream_create_priority(int(priority), C.byref(out)), "stream_create_priority")
+    _CREATED_STREAMS.append(int(out.value))
     return int(out.value)
+
+
+_CREATED_STREAMS = []       # hipStream_t handles made through the C ABI (torch's ExternalStream does not own them)
+
+
+def stream_destroy_all():
+    """Destroy every stream stream_create_cumask / stream_create_priority handed out (call once the ExternalStreams that
+    wrap them are no longer used: end of a run).  Idempotent."""
+    lib = L.load()
+    while _CREATED_STREAMS:
+        lib.sda_stream_destroy(C.c_void_p(_CREATED_STREAMS.pop()))
 
 
 def _need_cuda(*ts):
