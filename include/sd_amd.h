@@ -64,6 +64,8 @@ enum { SDA_EPI_GELU = 1,
                                        (conv1_wide.hip); takes SDA_EPI_GELU (+ y_pre), SDA_EPI_GELU_BWD (`stats` = one row per 256-row
                                        tile: sda_conv_stats_rows), SDA_EPI_ROW_SUMSQ (Cout_p % 256 == 0).  Any other shape with this
                                        flag is an error, not a fallback */
+       SDA_CONV_WAVE_PRIO = 1048576,/* the tile-per-workgroup kernels: the launch's waves run at s_setprio 3 (they win a SIMD's issue
+                                       arbitration against co-resident waves of other kernels) */
        SDA_EPI_GELU_BWD = 65536,    /* kernel size 1 (flat tiles or one tile per workgroup): the conv's output is the gradient entering a GELU whose input u = bn_x ([rows][Cout_p],
                                        same layout as y) the forward kept: y = round(conv) * GELU'(u) (what sda_gelu_backward_colsum
                                        computes from the stored gradient), `stats` rows (sda_conv_stats_rows) = per-unit column

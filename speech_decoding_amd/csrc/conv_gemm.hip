@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256 * NT, 2) void conv_gemm_kernel(const sda_conv_a
   constexpr int CH = Vec16<E>::N;                       // channels per thread in the epilogue: 16-byte global accesses
   using G = EpiGeom<TILE_CO, CH>;
 
+  // SDA_CONV_WAVE_PRIO: this kernel's waves win the per-SIMD issue arbitration against the waves of a kernel co-resident from
+  // another stream (the backward's data-gradient convs beside the weight-gradient GEMMs)
+  if (a.flags & SDA_CONV_WAVE_PRIO) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tsel = wid >> 2;                            // which of the NT tiles this wave works on

@@ -15,6 +15,18 @@ namespace sda {
 // coefficient loads — with both, the BatchNorm/GELU passes were VALU-bound (≈ 4.3 TB/s), not HBM-bound.
 // Rows are taken U at a time: all loads of a batch are issued before the first use.
 // ------------------------------------------------------------------------------------------------
+// Wave priority of the backward's HBM-bound passes on the step's main chain (BatchNorm backward, GLU / GELU backward with their
+// column sums and the small reductions behind them): they run beside the weight-gradient GEMMs of the other stream, and at
+// s_setprio 3 their loads and stores win the SIMD's issue arbitration against those waves.  Round 5, six alternations on
+// one box (ms per step): off 6.771, on 6.777; with the data-gradient convs' waves raised as well (SDA_CONV_WAVE_PRIO) 6.725
+// against 6.754 for those alone — the pair is worth 0.05 ms, either one alone nothing.  -DSDA_EW_BWD_PRIO=0 turns it off.
+#ifndef SDA_EW_BWD_PRIO
+#define SDA_EW_BWD_PRIO 3
+#endif
+__device__ __forceinline__ void ew_bwd_prio() {
+  if constexpr (SDA_EW_BWD_PRIO > 0) __builtin_amdgcn_s_setprio(SDA_EW_BWD_PRIO);
+}
+
 struct RowWalk {
   int r, r1, step, T, b, t;
   __device__ RowWalk(int r0, int r1_, int step_, int T_) : r(r0), r1(r1_), step(step_), T(T_) {
@@ -584,6 +596,7 @@ template <typename E, int MODE>
 __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x, const E* __restrict__ dy,
                                                          E* __restrict__ dx, float* __restrict__ partial, int B, int T,
                                                          int Ch, const E* __restrict__ gate = nullptr) {
+  ew_bwd_prio();
   extern __shared__ float red[];
   constexpr int CH = Vec16<E>::N;
   const int nch = Ch / CH;
@@ -650,6 +663,7 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
 // sums[which][c] = sum over blocks (fp64, fixed order)
 __global__ __launch_bounds__(256) void col_reduce_final_kernel(const float* __restrict__ partial, int nblocks,
                                                                float* __restrict__ out0, float* __restrict__ out1, int Cp) {
+  ew_bwd_prio();
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double s0, s1;
   block_partial_sums(partial, nblocks, Cp, blockIdx.x * 8, out1 != nullptr, s0, s1);
@@ -680,6 +694,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_coef_kernel(const float* __r
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 int C, float inv_count, float* __restrict__ dbeta,
                                                                 float* __restrict__ dgamma, float* __restrict__ coef, int Cp) {
+  ew_bwd_prio();
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double s0, s1;
   block_partial_sums(partial, nrows, Cp, blockIdx.x * 8, true, s0, s1);
@@ -701,6 +716,7 @@ template <typename E, bool DG = false>
 __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(const E* __restrict__ dy, const E* __restrict__ x,
                                                                 const float* __restrict__ coef, E* __restrict__ dx,
                                                                 int B, int T, int Cp) {
+  ew_bwd_prio();
   constexpr int CH = Vec16<E>::N, U = 2;
   const int nch = Cp / CH;
   const int RG = nch >= 256 ? 1 : 256 / nch;

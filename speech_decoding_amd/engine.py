@@ -162,6 +162,10 @@ class EncoderEngine:
         self.wide_1x1_forward = True         # conv_final2's forward (widths that are multiples of 256)
         self.wide_1x1_forward_all = False    # ... conv_final1's as well (320-channel tiles: equal to the tile kernel)
         self.wide_1x1_backward = False
+        self.dgrad_wave_priority = True      # the backward's tile-kernel data gradients at s_setprio 3 (SDA_CONV_WAVE_PRIO): with the
+                                             # HBM-bound passes of the chain raised as well (elementwise.hip, SDA_EW_BWD_PRIO) the
+                                             # step's chain wins each SIMD's issue arbitration against the weight-gradient GEMMs it
+                                             # runs beside: 6.725 against 6.771 ms, six alternations (either one alone: nothing)
         self.flat_1x1_options = 0            # extra conv1_flat flags (1024 = staggered tile order, 32768 = one workgroup per CU)
         # CU partition for backward (experiment, default off): k > 0 gives the data-gradient chain (the stream backward() is
         # called on hands over to a CU-masked stream) k of the 8 XCDs and the weight-gradient stream the other 8 - k, instead
@@ -698,6 +702,8 @@ class EncoderEngine:
             the gradient entering that block's F.glu, and the epilogue writes the GLU backward [d value | d gate] into `out`
             (twice as wide) plus the per-tile column sums of both halves (second value) instead of the gradient itself."""
             bflags = (L.CONV_FLAT_TILES | (L.CONV_ONE_PER_CU if self.flat_backward_one_per_cu else 0)) if (self.flat_tiles_backward and KS == 3) else 0
+            if self.dgrad_wave_priority and not bflags:
+                bflags |= L.CONV_WAVE_PRIO
             if glu_bwd is not None:
                 st = torch.empty((ops.conv_stats_rows(B, T, KS, Cin_p, 0), 2, Cin_p), dtype=torch.float32, device=dev)
                 ops.conv_gemm(dy, ctx.packed_T[key], out, B=B, T=T, KS=KS, dil=dil, res=res, widx=widx, stats=st, glu_bwd=glu_bwd,

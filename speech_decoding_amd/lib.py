@@ -18,6 +18,7 @@ CH_ALIGN = 64
 EPI_GELU, EPI_GLU, EPI_GLU_BWD = 1, 2, 4
 EPI_GELU_BWD, EPI_ROW_SUMSQ, EPI_BN_STORE_DG = 65536, 131072, 262144          # epilogues of conv1_flat only (need CONV_FLAT_TILES)
 CONV_SINGLE_TILE, CONV_PAIR_TILES, CONV_FLAT_TILES, CONV_ONE_PER_CU = 4096, 8192, 16384, 32768
+CONV_WAVE_PRIO = 1048576      # the launch's waves at s_setprio 3
 CONV_WIDE_TILES = 524288      # kernel size 1 on 256-row x 256 / 320-channel tiles, one 8-wave workgroup per CU (conv1_wide.hip)
 WGRAD_FLAT_ROWS = 1
 
