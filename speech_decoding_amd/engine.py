@@ -459,7 +459,8 @@ class EncoderEngine:
                     ops.conv_gemm(x, w, h, B=B, T=T, KS=3, dil=dil[j], bias=bias, res=res, stats=stats, alg_dims=alg,
                                   flags=k3_flags)
                     if self.group is not None:   # one 2*Cp-float all-reduce per BatchNorm
-                        stats = ops.reduce_slabs(stats).reshape(1, 2, d.D2p)
+                        # (the column-sum kernel, ~10 us; the generic slab sum took 34 us per BatchNorm on this chain)
+                        stats = ops.reduce_stats(stats).view(1, 2, d.D2p)
                         self._allreduce(stats)
                         nt = 1
                     mean, rstd, scale, shift, bcoef = ops.bn_finalize(stats, nt, count, P[bnp + "w"], P[bnp + "b"],
@@ -832,7 +833,12 @@ class EncoderEngine:
                                                   dy_is_dg=bool(self.bn_backward_store_dg and tstats is not None))
                 # under DP the sums are already global on every rank; the gradient all-reduce (SUM) follows
                 if sync:
-                    dgam, dbet = dgam / world, dbet / world
+                    # (one launch for both rows, on the weight-gradient stream: only the optimiser reads these)
+                    both = dgam._base if dgam._base is not None else torch.stack([dgam, dbet])
+                    if side is not None:
+                        both.record_stream(side)
+                    scaled = on_side(lambda both=both: both / world)
+                    dgam, dbet = scaled[0], scaled[1]
                 grads[bnp + "w"], grads[bnp + "b"] = dgam[: d.D2], dbet[: d.D2]
                 src = bufs[f"b{k}.a0"] if j == 1 else x_in
                 ci, ci_p = (d.D2, d.D2p) if j == 1 else (cin, cin_p)
