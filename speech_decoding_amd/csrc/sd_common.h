@@ -183,6 +183,22 @@ template <> __device__ inline f32x4 mma16<float>(const uint4& a, const uint4& b,
   return c;
 }
 
+// The 32 x 32 output block form: v_mfma_f32_32x32x16 (16-bit storage only).  Lane l supplies row (l & 31) of either operand,
+// k = 8 * (l >> 5) + 0..7 — one 16-byte chunk; a 64-byte K-step is two of them (chunks {0, 1}, then {2, 3}).  Register v of the
+// result: row 8 * (v >> 2) + 4 * (l >> 5) + (v & 3) of the FIRST operand's block, column l & 31 = row of the second operand's.
+// Why: one wave issues a 16x16x32 every ~24 clocks although the instruction occupies the pipe for 16 (bare loop, one wave per
+// SIMD: 1.61 PFLOP/s; two waves 2.0; four 2.2), a 32x32x16 every 32 = its pipe time (2.45 PFLOP/s from ONE wave per SIMD):
+// tools/probes/sclk_probe.hip.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+template <typename E> __device__ inline f32x16 mma32(const uint4& a, const uint4& b, f32x16 c);
+template <> __device__ inline f32x16 mma32<uint16_t>(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&a), *reinterpret_cast<const bf16x8_t*>(&b), c, 0, 0, 0);
+}
+template <> __device__ inline f32x16 mma32<half_t>(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
+}
+
 // One MFMA row: acc[n] += a x b[n] for n < N.  16-bit types: N MFMAs.  fp32: the 16-deep K-step is four 16x16x4 MFMAs per
 // accumulator — issued j-OUTER, n-inner, so that consecutive MFMAs are independent and each accumulator is updated in place
 // (the accumulation order per accumulator is unchanged: j = 0, 1, 2, 3 — bit-equal results).  Written n-outer (four

@@ -35,7 +35,10 @@ constexpr int SG_NS = 4;                           // LDS stages; SG_NS - 1 slab
                                                    // five stages, 160 KB: 570 vs 590 us at 2048 x 256, 107 vs 103 at 256 x 256)
 constexpr int SG_PPW = 4;                          // 1 KB pieces per wave and slab: 2 of W + 2 of X (8 waves x 4 = 32 pieces)
 
-template <typename E, int NS>
+// M32: the K-step on v_mfma_f32_32x32x16 (sd_common.h, mma32): per wave 4 (j) x 2 (i) blocks of 32 x 32, two MFMAs each per
+// K-step; the 64-byte rows' swizzle is then chunk ^ ((row >> 2) & 3) — a 16-lane service group of ds_read_b128 (conv_tile.h)
+// holds the row quads {0, 3, 5, 6} or {1, 2, 4, 7} of ONE chunk.
+template <typename E, int NS, bool M32>
 __global__ __launch_bounds__(512, 2) void sim_gemm_kernel(const E* __restrict__ X, const E* __restrict__ W, float* __restrict__ partial,
                                                            const int M, const int N, const int Np, const long pitch, const int nslab,
                                                            const int ksplit, const int m_tiles, const int n_tiles) {
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void sim_gemm_kernel(const E* __restrict__ 
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int r = (wid + 8 * h) * 16 + prow;                       // row of the tile
-    const int sw = (pchunk ^ sw64(r)) * PER16;
+    const int sw = (pchunk ^ (M32 ? ((r >> 2) & 3) : sw64(r))) * PER16;
     const long xr = min((long)r, (long)(M - 1 - m0)), wr = min((long)r, (long)(N - 1 - n0));      // clamped: never stored
     xoff[h] = (uint32_t)((xr * pitch + sw) * (long)sizeof(E));
     woff[h] = (uint32_t)((wr * pitch + sw) * (long)sizeof(E));
@@ -92,11 +95,22 @@ __global__ __launch_bounds__(512, 2) void sim_gemm_kernel(const E* __restrict__ 
   };
   auto advance = [&]() { xs += SLAB; ws += SLAB; };
 
-  f32x4 acc[8][4];
+  f32x4 acc[M32 ? 1 : 8][M32 ? 1 : 4];
+  f32x16 acc32[M32 ? 4 : 1][M32 ? 2 : 1];
+  if constexpr (M32) {
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc32[a][b][v] = 0.f;
+  } else {
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int l32 = lane & 31, lh = lane >> 5;
 
   constexpr int D = NS - 1;
 #pragma unroll
@@ -121,6 +135,22 @@ __global__ __launch_bounds__(512, 2) void sim_gemm_kernel(const E* __restrict__ 
     const unsigned char* xsm = wsm + SG_OP_BYTES;              // X rows (second operand -> accumulator columns = i)
     // all twelve fragments of the K-step are requested at once, right behind the barrier
     uint4 bf[4], af[8];
+    if constexpr (M32) {
+      auto at = [&](int row, int chunk) { return row * ROW_B + ((chunk ^ ((row >> 2) & 3)) << 4); };
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = *reinterpret_cast<const uint4*>(xsm + at(wi * 64 + (b >> 1) * 32 + l32, 2 * (b & 1) + lh));
+#pragma unroll
+      for (int a = 0; a < 8; ++a) af[a] = *reinterpret_cast<const uint4*>(wsm + at(wj * 128 + (a >> 1) * 32 + l32, 2 * (a & 1) + lh));
+      // af[2 A + h], bf[2 B + h]: block A / B, K half h; h outer, so an accumulator block comes round every eighth MFMA
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc32[a][b] = mma32<E>(af[2 * a + h], bf[2 * b + h], acc32[a][b]);
+          if ((a & 1) && more) issue(nxt, 2 * h + (a >> 1));
+        }
+    } else {
 #pragma unroll
     for (int b = 0; b < 4; ++b) bf[b] = *reinterpret_cast<const uint4*>(xsm + lds_sw64(wi * 64 + b * 16 + lr, lq));
 #pragma unroll
@@ -132,6 +162,7 @@ __global__ __launch_bounds__(512, 2) void sim_gemm_kernel(const E* __restrict__ 
       // slab s + D's pieces go out behind MFMA rows 1, 3, 5, 7: the matrix pipe works through the issue
       if ((a & 1) && more) issue(nxt, a >> 1);
     }
+    }
     if (more) advance();
     cur = cur == NS - 1 ? 0 : cur + 1;
   }
@@ -139,6 +170,26 @@ __global__ __launch_bounds__(512, 2) void sim_gemm_kernel(const E* __restrict__ 
   // K-split partial sums: lane (lq, lr) of block (a, b) holds S[i][j .. j + 3], i = m0 + wi * 64 + b * 16 + lr,
   // j = n0 + wj * 128 + a * 16 + 4 * lq
   float* __restrict__ P = partial + (size_t)ks * M * Np;
+  if constexpr (M32) {
+    // block (a, b), register v: S[i][j], i = m0 + wi * 64 + b * 32 + (lane & 31), j = n0 + wj * 128 + a * 32 + 8 * (v >> 2) +
+    // 4 * (lane >> 5) + (v & 3): four consecutive j per register quad
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int i = m0 + wi * 64 + b * 32 + l32;
+      if (i < M) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int j = n0 + wj * 128 + a * 32 + 8 * g + 4 * lh;
+            if (j + 3 < Np)
+              *reinterpret_cast<f32x4*>(P + (size_t)i * Np + j) =
+                  f32x4{acc32[a][b][4 * g], acc32[a][b][4 * g + 1], acc32[a][b][4 * g + 2], acc32[a][b][4 * g + 3]};
+          }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     const int i = m0 + wi * 64 + b * 16 + lr;
@@ -156,7 +207,8 @@ template <typename E, int NS>
 int launch_sim_ns(const void* X, const void* W, float* partial, int M, int N, int Np, long K, long pitch, int ksplit, hipStream_t st) {
   constexpr int lds = NS * SG_STAGE;
   static unsigned long long attr_done = 0;        // per device
-  auto kern = sim_gemm_kernel<E, NS>;
+  static const bool m32 = []() { const char* e = getenv("SDA_SIM_MFMA32"); return !e || atoi(e) != 0; }();
+  auto kern = m32 ? sim_gemm_kernel<E, NS, true> : sim_gemm_kernel<E, NS, false>;
   if (first_use_on_device(attr_done)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       set_error("sim_gemm: cannot reserve %d bytes of LDS", lds);
