@@ -229,7 +229,8 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            from speech_decoding_amd.distributed import init_process_group as sda_init_pg
+            sda_init_pg("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
     elif emu > 1:
@@ -240,7 +241,8 @@ def main():
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         kw = dict(device_id=dev) if backend == "nccl" else {}
-        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
+        from speech_decoding_amd.distributed import init_process_group as sda_init_pg
+        sda_init_pg(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
         from speech_decoding_amd import distributed as sda_dist
         from speech_decoding_amd import loss as _l
         sda_dist.emulate_world(emu)

@@ -33,6 +33,22 @@ def active_group():
     return None
 
 
+def init_process_group(backend: str = "nccl", **kw):
+    """dist.init_process_group with RCCL's stream of the DEFAULT group at high priority: that group carries the step's
+    latency-bound collectives (the 2 * Cp-float BatchNorm all-reduces, the row-statistics gather — each one a wait on the
+    high-priority training stream's chain), which would otherwise queue behind the normal-priority weight-gradient GEMMs for
+    CUs.  The bulk communicators (side_group: "gather", "grads") keep the default priority.  SDA_RCCL_HIGH_PRIORITY=0 turns
+    it off.  By design, not by measurement: at world size 1 RCCL launches no kernel, and no multi-GPU box was available."""
+    if backend == "nccl" and os.environ.get("SDA_RCCL_HIGH_PRIORITY", "1") != "0" and "pg_options" not in kw:
+        try:
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            kw["pg_options"] = opts
+        except (AttributeError, RuntimeError):
+            pass
+    return dist.init_process_group(backend, **kw)
+
+
 _EMULATED_WORLD = 1
 
 

@@ -84,7 +84,8 @@ def run(args, train_batches: Optional[Callable] = None, test_batch: Optional[Cal
     use_training_stream(device)          # the loop's chain on a high-priority stream; the engine's side streams stay normal
     owns_group = world > 1 and not dist.is_initialized()
     if owns_group:
-        dist.init_process_group(os.environ.get("SDA_DIST_BACKEND", "nccl"))
+        from speech_decoding_amd.distributed import init_process_group as sda_init_pg
+        sda_init_pg(os.environ.get("SDA_DIST_BACKEND", "nccl"))
     if args.get("reproducible", False):
         np.random.seed(0)
         torch.manual_seed(0)
