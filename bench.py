@@ -332,11 +332,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_enqueue = [0.0]
+
     def timed(n, first, **kw):
         fence()
         t0 = time.perf_counter()
         for i in range(n):
             loss = step(first + i, **kw)
+        host_enqueue[0] = (time.perf_counter() - t0) / max(1, n)     # the host's share: it runs ahead of the GPU when this < the step
         fence()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], device=dev)
@@ -362,6 +365,7 @@ def main():
         step(i)
     ranks_acc.clear()
     dt, loss = timed(a.steps, a.warmup)                      # the contract number: K clean steps
+    host_main = host_enqueue[0]
     cnt = torch.cat([c.to(dev) for c in ranks_acc[-3:]]).float()
     top10_train = float((cnt < 10).float().mean())           # on the batches the last three steps trained on (for reference)
     final_loss = float(loss.detach())
@@ -512,6 +516,7 @@ def main():
             "top10_note": f"held-out batch of {B * world} segments never trained on (eval mode, chance = {10.0 / (B * world * emu):.4f}); "
                           f"on the last three TRAINING batches: {top10_train:.4f}",
             "final_loss": round(final_loss, 4),
+            "host_enqueue_ms_per_step": round(1e3 * host_main, 3),      # < ms_per_step: the host keeps ahead, the GPU is the limit
         }
         if dt_sync is not None:
             out["host_synced"] = {"value": round(B * world / dt_sync, 2), "ms_per_step": round(1e3 * dt_sync, 3),

@@ -634,8 +634,13 @@ class EncoderEngine:
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
-            with torch.cuda.stream(side):
+            # (set_stream both ways instead of the torch.cuda.stream() context: ~40 calls per backward, and the context
+            # manager costs the host 15-20 us a time; backward() is entered on `main` and nothing in `fn` leaves a third stream current)
+            torch.cuda.set_stream(side)
+            try:
                 out = fn()
+            finally:
+                torch.cuda.set_stream(main)
             for t in (out if isinstance(out, (tuple, list)) else (out,)):
                 t.record_stream(main)
             return out
