@@ -16,7 +16,7 @@ def timeit(fn, n=20, warm=3):
 def main():
     dev = "cuda:0"
     B, T = 256, 360
-    for dtype in (torch.bfloat16,):
+    for dtype in ((torch.float32,) if os.environ.get("DTYPE") == "fp32" else (torch.bfloat16,)):
         for (cin, cout, KS, dil) in [(320, 320, 3, 4), (320, 640, 3, 2)]:
             x = ops.new_rows(B, T, cin, dtype, dev); x.normal_()
             w = torch.randn(cout, cin, KS, device=dev) / math.sqrt(KS * cin)

@@ -17,7 +17,7 @@ def timeit(fn, n=20, warm=3):
 
 dev = "cuda:0"
 B, T = 256, 360
-dt = torch.bfloat16
+dt = torch.float32 if os.environ.get("DTYPE") == "fp32" else torch.bfloat16
 print("SDA_WGRAD_PF =", os.environ.get("SDA_WGRAD_PF", "(default)"))
 for (cin, cout, KS, dil, wgs) in [(320, 320, 3, 4, 256), (320, 320, 3, 4, 512), (320, 640, 3, 2, 256), (320, 640, 3, 2, 512),
                                   (640, 1024, 1, 0, 256), (640, 1024, 1, 0, 512), (320, 640, 1, 0, 256), (256, 320, 3, 1, 256)]:
@@ -32,6 +32,7 @@ for (cin, cout, KS, dil, wgs) in [(320, 320, 3, 4, 256), (320, 320, 3, 4, 512), 
     us = timeit(lambda: ops.wgrad_gemm(dy, x, B=B, T=T, KS=KS, dil=dil, perm=None, seg_start=seg, nseg=nseg, flat_rows=True))
     print(f"wgrad {cin:4d}->{cout:4d} k{KS} tiles {ntiles:3d} nseg {nseg:3d} ({ntiles * nseg:4d} wgs) {us:8.1f} us  {fl / us / 1e6:7.1f} TF", flush=True)
 F = 1024
+if dt == torch.float32: sys.exit(0)
 for Bm, Bn in [(256, 256), (2048, 256)]:
     Yt = ops.new_rows(Bm, T, F, dt, dev); Zt = ops.new_rows(Bn, T, F, dt, dev)
     ops.rows_view(Yt, Bm, F, T).normal_(); ops.rows_view(Zt, Bn, F, T).normal_()
