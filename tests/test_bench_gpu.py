@@ -65,6 +65,7 @@ def test_bench_single_gpu_line_carries_the_contract_fields():
                 "dtype", "data", "config", "roofline"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["dtype"] == "bf16" and line["vs_baseline"] is None
+    assert line["host_enqueue_ms_per_step"] > 0          # the host's share of the timed region (it runs ahead when < ms_per_step)
     r = line["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
 

@@ -13,7 +13,10 @@ from oracle import brain_oracle as O
 
 def _worker(rank, world, port, fn, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (the package's own entry point: the RCCL stream-priority option of backend "nccl" does not apply to gloo, the call must
+    # pass everything else through)
+    from speech_decoding_amd.distributed import init_process_group
+    init_process_group("gloo", rank=rank, world_size=world)
     try:
         ret[rank] = fn(rank, world)
     finally:
