@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int C, float* __restrict__ partial, int B, int T, int Cp) {
-  extern __shared__ float red[];
+  extern __shared__ __attribute__((aligned(16))) float red[];
   constexpr int CH = Vec16<E>::N;
   const int nch = Cp / CH;
   const int RG = 256 / nch;
@@ -585,6 +585,13 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const E* __restrict__ d
   }
 }
 
+// padding (in float4) behind a row group of bwd_colsum_kernel's LDS image: (2 * (CH / 4) * nch + pad) = nch (mod 16)
+__host__ __device__ inline int bwd_colsum_pad(int nch, int CH) { return (((nch - 2 * (CH / 4) * nch) % 16) + 16) % 16; }
+static inline size_t bwd_colsum_lds(int Ch, int dtype) {
+  const int CH = dtype == SDA_F32 ? 4 : 8, nch = Ch / CH, RG = 256 / nch;
+  return (size_t)RG * (2 * (CH / 4) * nch + bwd_colsum_pad(nch, CH)) * 16;
+}
+
 // Backward elementwise stage fused with the column sums of its own output (bias gradients of the layer
 // below), same thread->channel ownership as col_reduce_kernel.
 //   MODE 0 (GELU):  du = dz * GELU'(u);  partial[blk][0][c] = sum du
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
                                                          E* __restrict__ dx, float* __restrict__ partial, int B, int T,
                                                          int Ch, const E* __restrict__ gate = nullptr) {
   ew_bwd_prio();
-  extern __shared__ float red[];
+  extern __shared__ __attribute__((aligned(16))) float red[];
   constexpr int CH = Vec16<E>::N;
   const int nch = Ch / CH;
   const int RG = 256 / nch;
@@ -642,12 +649,15 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
       }
     }
   }
-  // (LDS image as in col_reduce_kernel: [row group][which][quarter][chunk] float4, conflict-free stores)
+  // (LDS image as in col_reduce_kernel: [row group][which][quarter][chunk] float4; a row group's base is shifted so that
+  // base(rg + 1) = base(rg) + nch (mod 16 float4): the 16 lanes of a store that straddle two row groups — 320 channels: nch = 40,
+  // lanes 32..47 = chunks 32..39 of one group and 0..7 of the next — then still take 16 distinct 16-byte slots of a bank row)
+  const int rgs = 2 * (CH / 4) * nch + bwd_colsum_pad(nch, CH);            // float4 per row group
   if (rg < RG) {
 #pragma unroll
     for (int q4 = 0; q4 < CH / 4; ++q4) {
-      *reinterpret_cast<float4*>(red + ((((rg * 2 + 0) * (CH / 4) + q4) * nch + ch) << 2)) = make_float4(a0[4 * q4], a0[4 * q4 + 1], a0[4 * q4 + 2], a0[4 * q4 + 3]);
-      *reinterpret_cast<float4*>(red + ((((rg * 2 + 1) * (CH / 4) + q4) * nch + ch) << 2)) = make_float4(a1[4 * q4], a1[4 * q4 + 1], a1[4 * q4 + 2], a1[4 * q4 + 3]);
+      *reinterpret_cast<float4*>(red + ((rg * rgs + (0 * (CH / 4) + q4) * nch + ch) << 2)) = make_float4(a0[4 * q4], a0[4 * q4 + 1], a0[4 * q4 + 2], a0[4 * q4 + 3]);
+      *reinterpret_cast<float4*>(red + ((rg * rgs + (1 * (CH / 4) + q4) * nch + ch) << 2)) = make_float4(a1[4 * q4], a1[4 * q4 + 1], a1[4 * q4 + 2], a1[4 * q4 + 3]);
     }
   }
   __syncthreads();
@@ -655,7 +665,7 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const E* __restrict__ x
     const int which = i / Ch, c = i - which * Ch;
     const int chc = c / CH, q4 = (c % CH) >> 2, e = c & 3;
     float sum = 0.f;
-    for (int g = 0; g < RG; ++g) sum += red[((((g * 2 + which) * (CH / 4) + q4) * nch + chc) << 2) + e];
+    for (int g = 0; g < RG; ++g) sum += red[((g * rgs + (which * (CH / 4) + q4) * nch + chc) << 2) + e];
     partial[((size_t)blockIdx.x * 2 + which) * Ch + c] = sum;
   }
 }
@@ -1285,7 +1295,7 @@ extern "C" int sda_glu_backward_colsum(const void* x, const void* dy, void* dx, 
   if (!x || !dy || !dx || !scratch || Ch % 64 || Ch > 1024 || !fits_u32(B, T, 2L * Ch)) { set_error("glu_backward_colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const size_t lds = (size_t)(256 / (Ch / (dtype == SDA_F32 ? 4 : 8))) * 2 * Ch * sizeof(float);
+  const size_t lds = bwd_colsum_lds(Ch, dtype);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 1>), dim3(nb), dim3(256), lds, st, (const E*)x,
                                          (const E*)dy, (E*)dx, scratch, B, T, Ch));
   if (colsum) hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
@@ -1297,7 +1307,7 @@ extern "C" int sda_glu_backward_colsum_og(const void* out, const void* gate, con
   if (!out || !gate || !dy || !dx || !scratch || Ch % 64 || Ch > 1024 || !fits_u32(B, T, 2L * Ch)) { set_error("glu_backward_colsum_og: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const size_t lds = (size_t)(256 / (Ch / (dtype == SDA_F32 ? 4 : 8))) * 2 * Ch * sizeof(float);
+  const size_t lds = bwd_colsum_lds(Ch, dtype);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 2>), dim3(nb), dim3(256), lds, st, (const E*)out,
                                          (const E*)dy, (E*)dx, scratch, B, T, Ch, (const E*)gate));
   if (colsum) hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Ch + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, colsum + Ch, Ch);
@@ -1309,7 +1319,7 @@ extern "C" int sda_gelu_backward_colsum(const void* u, const void* dz, void* du,
   if (!u || !dz || !du || !scratch || Cp % 64 || Cp > 1024 || !fits_u32(B, T, Cp)) { set_error("gelu_backward_colsum: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = red_blocks(B, T);
-  const size_t lds = (size_t)(256 / (Cp / (dtype == SDA_F32 ? 4 : 8))) * 2 * Cp * sizeof(float);
+  const size_t lds = bwd_colsum_lds(Cp, dtype);
   SDA_DISPATCH(dtype, hipLaunchKernelGGL((bwd_colsum_kernel<E, 0>), dim3(nb), dim3(256), lds, st, (const E*)u,
                                          (const E*)dz, (E*)du, scratch, B, T, Cp));
   if (colsum) hipLaunchKernelGGL(col_reduce_final_kernel, dim3((Cp + 7) / 8), dim3(256), 0, st, scratch, nb, colsum, (float*)nullptr, Cp);
